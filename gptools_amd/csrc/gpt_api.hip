@@ -1,0 +1,763 @@
+// C ABI of libgptools_hip.so (see include/gptools_hip.h): context, plan cache, path dispatch, and the
+// host-pointer staging entry points that the Stan user header binds.
+#include "../../include/gptools_hip.h"
+#include "gpt_common.h"
+#include "gpt_host.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+struct gpt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::map<int, cplx*> tw; // twiddle tables w_n^m, keyed by n
+    cplx* ws = nullptr;      // packed-spectrum workspace of the three-pass paths
+    size_t ws_bytes = 0;
+    double* partials = nullptr;
+    size_t partials_bytes = 0;
+    char* arena = nullptr; // device staging arena of the host-pointer entry points
+    size_t arena_bytes = 0;
+    double* pinned = nullptr; // small pinned scratch for scalar read-backs
+    std::string err;
+    double last_min_eig = NAN;
+};
+
+namespace {
+
+int fail(gpt_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+int hip_fail(gpt_ctx* c, hipError_t e, const char* what) {
+    return fail(c, e == hipErrorOutOfMemory ? GPT_ERR_ALLOC : GPT_ERR_HIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(c, expr)                                                                                       \
+    do {                                                                                                       \
+        hipError_t e__ = (expr);                                                                               \
+        if (e__ != hipSuccess) return hip_fail((c), e__, #expr);                                               \
+    } while (0)
+
+template <typename T> int ensure(gpt_ctx* c, T*& ptr, size_t& have, size_t need) {
+    if (need <= have) return GPT_OK;
+    if (ptr) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(ptr));
+        ptr = nullptr;
+        have = 0;
+    }
+    void* p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, need));
+    ptr = reinterpret_cast<T*>(p);
+    have = need;
+    return GPT_OK;
+}
+
+int get_twiddles(gpt_ctx* c, int n, const cplx** out) {
+    auto it = c->tw.find(n);
+    if (it != c->tw.end()) {
+        *out = it->second;
+        return GPT_OK;
+    }
+    std::vector<cplx> h((size_t)n);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int m = 0; m < n; ++m) {
+        // exact octant values where they exist, long-double elsewhere
+        const long double ang = two_pi * (long double)m / (long double)n;
+        long double cr = cosl(ang), si = -sinl(ang);
+        if ((4LL * m) % n == 0) {
+            const int q = (int)((4LL * m) / n) & 3;
+            cr = (q == 0) ? 1.0L : (q == 2) ? -1.0L : 0.0L;
+            si = (q == 1) ? -1.0L : (q == 3) ? 1.0L : 0.0L;
+        }
+        h[(size_t)m] = make_double2((double)cr, (double)si);
+    }
+    void* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, sizeof(cplx) * (size_t)n));
+    HIP_TRY(c, hipMemcpy(d, h.data(), sizeof(cplx) * (size_t)n, hipMemcpyHostToDevice));
+    c->tw[n] = reinterpret_cast<cplx*>(d);
+    *out = reinterpret_cast<cplx*>(d);
+    return GPT_OK;
+}
+
+int make_plan(gpt_ctx* c, int n, LinePlan& p) {
+    p.n = n;
+    p.ns = 0;
+    int m = n;
+    auto push = [&](int r) {
+        if (p.ns < GPT_MAX_STAGES) p.r[p.ns] = r;
+        p.ns++;
+    };
+    while (m % 4 == 0) { push(4); m /= 4; }
+    while (m % 2 == 0) { push(2); m /= 2; }
+    for (int f = 3; (int64_t)f * f <= m; f += 2)
+        while (m % f == 0) { push(f); m /= f; }
+    if (m > 1) push(m);
+    if (p.ns > GPT_MAX_STAGES) return fail(c, GPT_ERR_UNSUPPORTED, "too many FFT stages");
+    return get_twiddles(c, n, &p.tw);
+}
+
+int path_for_shape(int64_t H, int64_t W) {
+    if (H < 1 || W < 1 || H * W > 2147483647LL) return -1;
+    if (gpt_small_fits((int)H, (int)W, nullptr, nullptr)) return 0;
+    if (gpt_pow2_supported((int)H, (int)W)) return 1;
+    if (gpt_generic_supported((int)H, (int)W)) return 2;
+    return -1;
+}
+
+int check_shape(gpt_ctx* c, int64_t H, int64_t W, int64_t batch, int dim1) {
+    if (!c) return GPT_ERR_SHAPE;
+    if (H < 1 || W < 1 || batch < 0) return fail(c, GPT_ERR_SHAPE, "height, width >= 1 and batch >= 0 required");
+    if (dim1 && H != 1) return fail(c, GPT_ERR_SHAPE, "1-D functions take height == 1");
+    // n = height * width is a 32-bit Stan int in the reference (fft2.stan:15)
+    if (H * W > 2147483647LL) return fail(c, GPT_ERR_SHAPE, "height * width exceeds the reference's 32-bit int");
+    return GPT_OK;
+}
+
+int run_lattice(gpt_ctx* c, int op, LatArgs a) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (a.batch == 0) return GPT_OK;
+    int rc;
+    if ((rc = make_plan(c, a.W, a.pw)) != GPT_OK) return rc;
+    if ((rc = make_plan(c, a.H, a.ph)) != GPT_OK) return rc;
+    const int path = path_for_shape(a.H, a.W);
+    if (path == 0) {
+        HIP_TRY(c, gpt_launch_small(op, a, c->stream));
+        return GPT_OK;
+    }
+    if (path < 0) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "no kernel for a %d x %d lattice in this build", a.H, a.W);
+        return fail(c, GPT_ERR_UNSUPPORTED, buf);
+    }
+    // Three-pass paths: lattices are processed in chunks that share one packed-spectrum workspace, kept
+    // small enough (<= ~128 MiB) to stay resident in the 256 MiB Infinity Cache between the passes.
+    const size_t per = path == 1 ? gpt_pow2_workspace_bytes(a.H, a.W) : gpt_generic_workspace_bytes(a.H, a.W);
+    const int nblk = path == 1 ? gpt_pow2_col_blocks(a.H, a.W) : gpt_generic_col_blocks(a.H, a.W);
+    int64_t chunk = (int64_t)((size_t)(128u << 20) / per);
+    if (chunk < 1) chunk = 1;
+    if (chunk > a.batch) chunk = a.batch;
+    if (chunk > 32768) chunk = 32768;
+    if ((rc = ensure(c, c->ws, c->ws_bytes, per * (size_t)chunk)) != GPT_OK) return rc;
+    if ((rc = ensure(c, c->partials, c->partials_bytes, sizeof(double) * GPT_PART * (size_t)nblk * (size_t)chunk)) !=
+        GPT_OK)
+        return rc;
+    const int64_t hw = (int64_t)a.H * a.W, hwf = (int64_t)a.H * (a.W / 2 + 1);
+    for (int64_t b0 = 0; b0 < a.batch; b0 += chunk) {
+        LatArgs s = a;
+        s.batch = (a.batch - b0 < chunk) ? a.batch - b0 : chunk;
+        if (s.x) s.x += b0 * a.x_bs;
+        if (s.loc) s.loc += b0 * a.loc_bs;
+        if (s.cov) s.cov += b0 * a.cov_bs;
+        if (s.aux) s.aux += b0 * a.aux_bs;
+        if (s.cin) s.cin += b0 * a.cin_bs;
+        if (s.out) s.out += b0 * hw;
+        if (s.out_cov) s.out_cov += b0 * hwf;
+        if (s.out_c) s.out_c += b0 * hwf;
+        if (s.out_lpdf) s.out_lpdf += b0;
+        if (s.min_eig) s.min_eig += b0;
+        if (path == 1) HIP_TRY(c, gpt_launch_pow2(op, s, c->ws, c->partials, c->stream));
+        else HIP_TRY(c, gpt_launch_generic(op, s, c->ws, c->partials, c->stream));
+    }
+    return GPT_OK;
+}
+
+LatArgs base_args(int64_t H, int64_t W, int64_t batch, int dim1) {
+    LatArgs a;
+    memset(&a, 0, sizeof a);
+    a.H = (int)H;
+    a.W = (int)W;
+    a.batch = batch;
+    a.dim1 = dim1 ? 1 : 0;
+    return a;
+}
+
+int run_elem(gpt_ctx* c, int op, ElemArgs e, bool reduces, int K, double add, double* out_sum, double* out_min) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (e.batch == 0) return GPT_OK;
+    const int nblk = gpt_elem_blocks(e.H, e.W);
+    const int64_t chunk_max = 32768;
+    int rc;
+    if (reduces) {
+        const int64_t chunk = e.batch < chunk_max ? e.batch : chunk_max;
+        if ((rc = ensure(c, c->partials, c->partials_bytes, sizeof(double) * GPT_PART * (size_t)nblk * (size_t)chunk)) !=
+            GPT_OK)
+            return rc;
+    }
+    const int64_t hw = (int64_t)e.H * e.W, hwf = (int64_t)e.H * (e.W / 2 + 1);
+    const int npar = e.dim1 ? 3 : 5;
+    for (int64_t b0 = 0; b0 < e.batch; b0 += chunk_max) {
+        ElemArgs s = e;
+        s.batch = (e.batch - b0 < chunk_max) ? e.batch - b0 : chunk_max;
+        if (s.in) s.in += b0 * e.in_bs;
+        if (s.cin) s.cin += b0 * e.cin_bs;
+        if (s.par) s.par += b0 * npar;
+        if (s.out) {
+            if (op == EL_UNPACK) s.out += b0 * hw;
+            else s.out += b0 * hwf;
+        }
+        if (s.cout) s.cout += b0 * (op == EL_EXPAND ? (int64_t)e.W : hwf);
+        HIP_TRY(c, gpt_launch_elem(op, s, c->partials, c->stream));
+        if (reduces)
+            HIP_TRY(c, gpt_launch_finalize(c->partials, nblk, s.batch, K, add, out_sum ? out_sum + b0 * K : nullptr,
+                                           out_min ? out_min + b0 : nullptr, c->stream));
+    }
+    return GPT_OK;
+}
+
+ElemArgs elem_args(int64_t H, int64_t W, int64_t batch, int dim1) {
+    ElemArgs e;
+    memset(&e, 0, sizeof e);
+    e.H = (int)H;
+    e.W = (int)W;
+    e.batch = batch;
+    e.dim1 = dim1 ? 1 : 0;
+    return e;
+}
+
+} // namespace
+
+// ===================================================================================================
+extern "C" {
+
+const char* gpt_version(void) { return "gptools_hip 0.1 (gfx950)"; }
+
+int gpt_create(int device, void* stream, gpt_ctx** out) {
+    if (!out) return GPT_ERR_SHAPE;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return GPT_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return GPT_ERR_HIP;
+    gpt_ctx* c = new gpt_ctx();
+    c->device = device;
+    c->stream = reinterpret_cast<hipStream_t>(stream); // NULL = HIP's default stream
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 4096, hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return GPT_ERR_ALLOC;
+    }
+    c->pinned = reinterpret_cast<double*>(p);
+    *out = c;
+    return GPT_OK;
+}
+
+int gpt_destroy(gpt_ctx* c) {
+    if (!c) return GPT_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->tw) (void)hipFree(kv.second);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->partials) (void)hipFree(c->partials);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    delete c;
+    return GPT_OK;
+}
+
+int gpt_set_stream(gpt_ctx* c, void* stream) {
+    if (!c) return GPT_ERR_SHAPE;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+    return GPT_OK;
+}
+
+int gpt_synchronize(gpt_ctx* c) {
+    if (!c) return GPT_ERR_SHAPE;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GPT_OK;
+}
+
+const char* gpt_last_error(const gpt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+double gpt_last_min_eig(const gpt_ctx* c) { return c ? c->last_min_eig : NAN; }
+int gpt_path_for_shape(int64_t H, int64_t W) { return path_for_shape(H, W); }
+
+// ---- real-FFT layer --------------------------------------------------------------------------------
+int gpt_rfft2(gpt_ctx* c, const double* y, int64_t H, int64_t W, int64_t batch, double* out_complex) {
+    int rc = check_shape(c, H, W, batch, 0);
+    if (rc) return rc;
+    LatArgs a = base_args(H, W, batch, 0);
+    a.x = y;
+    a.x_bs = H * W;
+    a.out_c = reinterpret_cast<cplx*>(out_complex);
+    return run_lattice(c, OP_RFFT2, a);
+}
+
+int gpt_inv_rfft2(gpt_ctx* c, const double* z_complex, int64_t H, int64_t W, int64_t batch, double* out) {
+    int rc = check_shape(c, H, W, batch, 0);
+    if (rc) return rc;
+    LatArgs a = base_args(H, W, batch, 0);
+    a.cin = reinterpret_cast<const cplx*>(z_complex);
+    a.cin_bs = H * (W / 2 + 1);
+    a.out = out;
+    return run_lattice(c, OP_INV_RFFT2, a);
+}
+
+int gpt_expand_rfft(gpt_ctx* c, const double* y_complex, int64_t n, int64_t batch, double* out_complex) {
+    int rc = check_shape(c, 1, n, batch, 1);
+    if (rc) return rc;
+    ElemArgs e = elem_args(1, n, batch, 1);
+    e.cin = reinterpret_cast<const cplx*>(y_complex);
+    e.cin_bs = n / 2 + 1;
+    e.cout = reinterpret_cast<cplx*>(out_complex);
+    return run_elem(c, EL_EXPAND, e, false, 0, 0.0, nullptr, nullptr);
+}
+
+// ---- GP layer --------------------------------------------------------------------------------------
+int gpt_gp_evaluate_rfft2_scale(gpt_ctx* c, const double* cov, int64_t cov_bs, int64_t H, int64_t W,
+                                int64_t batch, int dim1, double* out, double* min_eig) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    ElemArgs e = elem_args(H, W, batch, dim1);
+    e.in = cov;
+    e.in_bs = cov_bs;
+    e.out = out;
+    return run_elem(c, EL_SCALE, e, true, 0, 0.0, nullptr, min_eig);
+}
+
+int gpt_gp_unpack_rfft2(gpt_ctx* c, const double* z_complex, int64_t H, int64_t W, int64_t batch, int dim1,
+                        double* out) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    ElemArgs e = elem_args(H, W, batch, dim1);
+    e.cin = reinterpret_cast<const cplx*>(z_complex);
+    e.cin_bs = H * (W / 2 + 1);
+    e.out = out;
+    return run_elem(c, EL_UNPACK, e, false, 0, 0.0, nullptr, nullptr);
+}
+
+int gpt_gp_pack_rfft2(gpt_ctx* c, const double* z, int64_t H, int64_t W, int64_t batch, int dim1,
+                      double* out_complex) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    ElemArgs e = elem_args(H, W, batch, dim1);
+    e.in = z;
+    e.in_bs = H * W;
+    e.cout = reinterpret_cast<cplx*>(out_complex);
+    return run_elem(c, EL_PACK, e, false, 0, 0.0, nullptr, nullptr);
+}
+
+int gpt_gp_rfft2(gpt_ctx* c, const double* y, int64_t y_bs, const double* loc, int64_t loc_bs, const double* cov,
+                 int64_t cov_bs, int64_t H, int64_t W, int64_t batch, int dim1, double* z_out, double* min_eig) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    LatArgs a = base_args(H, W, batch, dim1);
+    a.x = y; a.x_bs = y_bs;
+    a.loc = loc; a.loc_bs = loc_bs;
+    a.cov = cov; a.cov_bs = cov_bs;
+    a.out = z_out;
+    a.min_eig = min_eig;
+    return run_lattice(c, OP_GP_RFFT2, a);
+}
+
+int gpt_gp_inv_rfft2(gpt_ctx* c, const double* z, int64_t z_bs, const double* loc, int64_t loc_bs,
+                     const double* cov, int64_t cov_bs, int64_t H, int64_t W, int64_t batch, int dim1,
+                     double* f_out, double* min_eig) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    LatArgs a = base_args(H, W, batch, dim1);
+    a.x = z; a.x_bs = z_bs;
+    a.loc = loc; a.loc_bs = loc_bs;
+    a.cov = cov; a.cov_bs = cov_bs;
+    a.out = f_out;
+    a.min_eig = min_eig;
+    return run_lattice(c, OP_GP_INV_RFFT2, a);
+}
+
+int gpt_gp_rfft2_log_abs_det_jac(gpt_ctx* c, const double* cov, int64_t cov_bs, int64_t H, int64_t W,
+                                 int64_t batch, int dim1, double* out, double* min_eig) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    ElemArgs e = elem_args(H, W, batch, dim1);
+    e.in = cov;
+    e.in_bs = cov_bs;
+    const int64_t n = H * W;
+    int64_t nterms = (n - 1) / 2;
+    if (H % 2 == 0 && W % 2 == 0) nterms -= 1;
+    // fft2.stan:167-171 / fft1.stan:81
+    const double add = -std::log(2.0) * (double)nterms + (double)n * std::log((double)n) / 2.0;
+    return run_elem(c, EL_LADJ, e, true, 1, add, out, min_eig);
+}
+
+int gpt_gp_rfft2_log_abs_det_jac_vjp(gpt_ctx* c, const double* cov, int64_t cov_bs, int64_t H, int64_t W,
+                                     int64_t batch, int dim1, double* grad_cov) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    ElemArgs e = elem_args(H, W, batch, dim1);
+    e.in = cov;
+    e.in_bs = cov_bs;
+    e.out = grad_cov;
+    return run_elem(c, EL_LADJ_VJP, e, false, 0, 0.0, nullptr, nullptr);
+}
+
+int gpt_gp_rfft2_lpdf(gpt_ctx* c, const double* y, int64_t y_bs, const double* loc, int64_t loc_bs,
+                      const double* cov, int64_t cov_bs, int64_t H, int64_t W, int64_t batch, int dim1,
+                      double* lpdf, double* min_eig) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    LatArgs a = base_args(H, W, batch, dim1);
+    a.x = y; a.x_bs = y_bs;
+    a.loc = loc; a.loc_bs = loc_bs;
+    a.cov = cov; a.cov_bs = cov_bs;
+    a.out_lpdf = lpdf;
+    a.min_eig = min_eig;
+    return run_lattice(c, OP_LPDF, a);
+}
+
+int gpt_gp_rfft2_lpdf_vjp(gpt_ctx* c, const double* y, int64_t y_bs, const double* loc, int64_t loc_bs,
+                          const double* cov, int64_t cov_bs, int64_t H, int64_t W, int64_t batch, int dim1,
+                          double* lpdf, double* grad_y, double* grad_cov, double* min_eig) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    if (!grad_y) return fail(c, GPT_ERR_SHAPE, "grad_y must not be null (use gpt_gp_rfft2_lpdf for the value)");
+    LatArgs a = base_args(H, W, batch, dim1);
+    a.x = y; a.x_bs = y_bs;
+    a.loc = loc; a.loc_bs = loc_bs;
+    a.cov = cov; a.cov_bs = cov_bs;
+    a.out = grad_y;
+    a.out_cov = grad_cov;
+    a.out_lpdf = lpdf;
+    a.min_eig = min_eig;
+    return run_lattice(c, OP_LPDF_VJP, a);
+}
+
+int gpt_gp_inv_rfft2_vjp(gpt_ctx* c, const double* z, int64_t z_bs, const double* cov, int64_t cov_bs,
+                         const double* fbar, int64_t fbar_bs, int64_t H, int64_t W, int64_t batch, int dim1,
+                         double* zbar, double* covbar) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    LatArgs a = base_args(H, W, batch, dim1);
+    a.x = z; a.x_bs = z_bs;
+    a.cov = cov; a.cov_bs = cov_bs;
+    a.aux = fbar; a.aux_bs = fbar_bs;
+    a.out = zbar;
+    a.out_cov = covbar;
+    return run_lattice(c, OP_INV_VJP, a);
+}
+
+int gpt_gp_rfft2_vjp(gpt_ctx* c, const double* y, int64_t y_bs, const double* loc, int64_t loc_bs,
+                     const double* cov, int64_t cov_bs, const double* zbar, int64_t zbar_bs, int64_t H, int64_t W,
+                     int64_t batch, int dim1, double* ybar, double* covbar) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    LatArgs a = base_args(H, W, batch, dim1);
+    a.x = y; a.x_bs = y_bs;
+    a.loc = loc; a.loc_bs = loc_bs;
+    a.cov = cov; a.cov_bs = cov_bs;
+    a.aux = zbar; a.aux_bs = zbar_bs;
+    a.out = ybar;
+    a.out_cov = covbar;
+    return run_lattice(c, OP_FWD_VJP, a);
+}
+
+// ---- spectral kernels ------------------------------------------------------------------------------
+static double gamma_ratio(double nu, int dim1) {
+    const double half_ndim = dim1 ? 0.5 : 1.0;
+    return std::tgamma(nu + half_ndim) / std::tgamma(nu); // fft1.stan:173, fft2.stan:245
+}
+
+int gpt_gp_periodic_exp_quad_cov_rfft2(gpt_ctx* c, int64_t H, int64_t W, const double* params, int64_t batch,
+                                       int dim1, double* out) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    ElemArgs e = elem_args(H, W, batch, dim1);
+    e.par = params;
+    e.out = out;
+    return run_elem(c, EL_EXPQUAD, e, false, 0, 0.0, nullptr, nullptr);
+}
+
+int gpt_gp_periodic_matern_cov_rfft2(gpt_ctx* c, double nu, int64_t H, int64_t W, const double* params,
+                                     int64_t batch, int dim1, double* out) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    if (!(nu > 0)) return fail(c, GPT_ERR_SHAPE, "nu must be positive");
+    ElemArgs e = elem_args(H, W, batch, dim1);
+    e.par = params;
+    e.out = out;
+    e.nu = nu;
+    e.gamma_ratio = gamma_ratio(nu, dim1);
+    return run_elem(c, EL_MATERN, e, false, 0, 0.0, nullptr, nullptr);
+}
+
+int gpt_gp_periodic_exp_quad_cov_rfft2_vjp(gpt_ctx* c, int64_t H, int64_t W, const double* params,
+                                           const double* covbar, int64_t covbar_bs, int64_t batch, int dim1,
+                                           double* params_bar) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    ElemArgs e = elem_args(H, W, batch, dim1);
+    e.par = params;
+    e.in = covbar;
+    e.in_bs = covbar_bs;
+    return run_elem(c, EL_EXPQUAD_VJP, e, true, dim1 ? 3 : 5, 0.0, params_bar, nullptr);
+}
+
+int gpt_gp_periodic_matern_cov_rfft2_vjp(gpt_ctx* c, double nu, int64_t H, int64_t W, const double* params,
+                                         const double* covbar, int64_t covbar_bs, int64_t batch, int dim1,
+                                         double* params_bar) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    if (!(nu > 0)) return fail(c, GPT_ERR_SHAPE, "nu must be positive");
+    ElemArgs e = elem_args(H, W, batch, dim1);
+    e.par = params;
+    e.in = covbar;
+    e.in_bs = covbar_bs;
+    e.nu = nu;
+    e.gamma_ratio = gamma_ratio(nu, dim1);
+    return run_elem(c, EL_MATERN_VJP, e, true, dim1 ? 3 : 5, 0.0, params_bar, nullptr);
+}
+
+} // extern "C"
+
+// ===================================================================================================
+// Host-pointer entry points: stage through a device arena, transposing Stan's column-major matrices.
+namespace {
+
+struct Stager {
+    gpt_ctx* c;
+    size_t off = 0;
+    int layout;
+    int rc = GPT_OK;
+    Stager(gpt_ctx* ctx, int lay, size_t need) : c(ctx), layout(lay) {
+        if (hipSetDevice(c->device) != hipSuccess) {
+            rc = fail(c, GPT_ERR_HIP, "hipSetDevice failed");
+            return;
+        }
+        rc = ensure(c, c->arena, c->arena_bytes, need);
+    }
+    void* bump(size_t bytes) {
+        void* p = c->arena + off;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    }
+    // upload an R x C matrix of esz-byte elements; returns a row-major device copy
+    const void* up(const void* host, int64_t R, int64_t C, int esz) {
+        if (rc != GPT_OK || !host) return nullptr;
+        const size_t bytes = (size_t)R * C * esz;
+        void* d = bump(bytes);
+        hipError_t e;
+        if (layout == GPT_COL_MAJOR && R > 1 && C > 1) {
+            void* t = bump(bytes);
+            e = hipMemcpyAsync(t, host, bytes, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = gpt_launch_transpose(t, d, (int)C, (int)R, 1, esz, c->stream);
+        } else {
+            e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->stream);
+        }
+        if (e != hipSuccess) rc = hip_fail(c, e, "upload");
+        return d;
+    }
+    void* dev(int64_t R, int64_t C, int esz) { return bump((size_t)R * C * esz); }
+    // download a row-major device R x C matrix into the caller's layout
+    void down(void* host, void* d, int64_t R, int64_t C, int esz) {
+        if (rc != GPT_OK || !host) return;
+        const size_t bytes = (size_t)R * C * esz;
+        hipError_t e;
+        if (layout == GPT_COL_MAJOR && R > 1 && C > 1) {
+            void* t = bump(bytes);
+            e = gpt_launch_transpose(d, t, (int)R, (int)C, 1, esz, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(host, t, bytes, hipMemcpyDeviceToHost, c->stream);
+        } else {
+            e = hipMemcpyAsync(host, d, bytes, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e != hipSuccess) rc = hip_fail(c, e, "download");
+    }
+    int finish(double* d_min_eig) {
+        if (rc != GPT_OK) return rc;
+        double mn = INFINITY;
+        if (d_min_eig) {
+            hipError_t e = hipMemcpyAsync(c->pinned, d_min_eig, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) return hip_fail(c, e, "min_eig read-back");
+        }
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_fail(c, e, "hipStreamSynchronize");
+        if (d_min_eig) {
+            mn = c->pinned[0];
+            c->last_min_eig = mn;
+            if (mn < 0) {
+                char buf[128];
+                snprintf(buf, sizeof buf, "covariance matrix is not positive-definite (minimum eigenvalue is %g)", mn);
+                return fail(c, GPT_ERR_NOT_PD, buf);
+            }
+        }
+        return GPT_OK;
+    }
+};
+
+size_t arena_need(int64_t H, int64_t W, int narrays) {
+    // every staged array may need a transposed twin; complex arrays count double
+    return (size_t)narrays * 2 * ((size_t)H * W * sizeof(double) + 256) + 4096;
+}
+
+} // namespace
+
+extern "C" {
+
+int gpt_gp_rfft2_host(gpt_ctx* c, int layout, const double* y, const double* loc, const double* cov, int64_t H,
+                      int64_t W, int dim1, double* z_out) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 5));
+    const double* dy = (const double*)s.up(y, H, W, 8);
+    const double* dl = (const double*)s.up(loc, H, W, 8);
+    const double* dc = (const double*)s.up(cov, H, Wf, 8);
+    double* dz = (double*)s.dev(H, W, 8);
+    double* dm = (double*)s.dev(1, 1, 8);
+    if (s.rc) return s.rc;
+    if ((rc = gpt_gp_rfft2(c, dy, 0, dl, 0, dc, 0, H, W, 1, dim1, dz, dm))) return rc;
+    s.down(z_out, dz, H, W, 8);
+    return s.finish(dm);
+}
+
+int gpt_gp_inv_rfft2_host(gpt_ctx* c, int layout, const double* z, const double* loc, const double* cov,
+                          int64_t H, int64_t W, int dim1, double* f_out) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 5));
+    const double* dz = (const double*)s.up(z, H, W, 8);
+    const double* dl = (const double*)s.up(loc, H, W, 8);
+    const double* dc = (const double*)s.up(cov, H, Wf, 8);
+    double* df = (double*)s.dev(H, W, 8);
+    double* dm = (double*)s.dev(1, 1, 8);
+    if (s.rc) return s.rc;
+    if ((rc = gpt_gp_inv_rfft2(c, dz, 0, dl, 0, dc, 0, H, W, 1, dim1, df, dm))) return rc;
+    s.down(f_out, df, H, W, 8);
+    return s.finish(dm);
+}
+
+int gpt_gp_rfft2_log_abs_det_jac_host(gpt_ctx* c, int layout, const double* cov, int64_t H, int64_t W, int dim1,
+                                      double* out, double* grad_cov) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 4));
+    const double* dc = (const double*)s.up(cov, H, Wf, 8);
+    double* dout = (double*)s.dev(1, 1, 8);
+    double* dm = (double*)s.dev(1, 1, 8);
+    double* dg = grad_cov ? (double*)s.dev(H, Wf, 8) : nullptr;
+    if (s.rc) return s.rc;
+    if ((rc = gpt_gp_rfft2_log_abs_det_jac(c, dc, 0, H, W, 1, dim1, dout, dm))) return rc;
+    if (grad_cov && (rc = gpt_gp_rfft2_log_abs_det_jac_vjp(c, dc, 0, H, W, 1, dim1, dg))) return rc;
+    s.down(out, dout, 1, 1, 8);
+    if (grad_cov) s.down(grad_cov, dg, H, Wf, 8);
+    return s.finish(dm);
+}
+
+int gpt_gp_rfft2_lpdf_host(gpt_ctx* c, int layout, const double* y, const double* loc, const double* cov,
+                           int64_t H, int64_t W, int dim1, double* lpdf, double* grad_y, double* grad_cov) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 7));
+    const double* dy = (const double*)s.up(y, H, W, 8);
+    const double* dl = (const double*)s.up(loc, H, W, 8);
+    const double* dc = (const double*)s.up(cov, H, Wf, 8);
+    double* dlp = (double*)s.dev(1, 1, 8);
+    double* dm = (double*)s.dev(1, 1, 8);
+    double* dgy = grad_y ? (double*)s.dev(H, W, 8) : nullptr;
+    double* dgc = (grad_y && grad_cov) ? (double*)s.dev(H, Wf, 8) : nullptr;
+    if (s.rc) return s.rc;
+    if (grad_y) rc = gpt_gp_rfft2_lpdf_vjp(c, dy, 0, dl, 0, dc, 0, H, W, 1, dim1, dlp, dgy, dgc, dm);
+    else rc = gpt_gp_rfft2_lpdf(c, dy, 0, dl, 0, dc, 0, H, W, 1, dim1, dlp, dm);
+    if (rc) return rc;
+    s.down(lpdf, dlp, 1, 1, 8);
+    if (grad_y) s.down(grad_y, dgy, H, W, 8);
+    if (dgc) s.down(grad_cov, dgc, H, Wf, 8);
+    return s.finish(dm);
+}
+
+int gpt_gp_inv_rfft2_vjp_host(gpt_ctx* c, int layout, const double* z, const double* cov, const double* fbar,
+                              int64_t H, int64_t W, int dim1, double* zbar, double* covbar) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 7));
+    const double* dz = (const double*)s.up(z, H, W, 8);
+    const double* dc = (const double*)s.up(cov, H, Wf, 8);
+    const double* dfb = (const double*)s.up(fbar, H, W, 8);
+    double* dzb = (double*)s.dev(H, W, 8);
+    double* dcb = covbar ? (double*)s.dev(H, Wf, 8) : nullptr;
+    if (s.rc) return s.rc;
+    if ((rc = gpt_gp_inv_rfft2_vjp(c, dz, 0, dc, 0, dfb, 0, H, W, 1, dim1, dzb, dcb))) return rc;
+    s.down(zbar, dzb, H, W, 8);
+    if (covbar) s.down(covbar, dcb, H, Wf, 8);
+    return s.finish(nullptr);
+}
+
+int gpt_gp_rfft2_vjp_host(gpt_ctx* c, int layout, const double* y, const double* loc, const double* cov,
+                          const double* zbar, int64_t H, int64_t W, int dim1, double* ybar, double* covbar) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 8));
+    const double* dy = (const double*)s.up(y, H, W, 8);
+    const double* dl = (const double*)s.up(loc, H, W, 8);
+    const double* dc = (const double*)s.up(cov, H, Wf, 8);
+    const double* dzb = (const double*)s.up(zbar, H, W, 8);
+    double* dyb = (double*)s.dev(H, W, 8);
+    double* dcb = covbar ? (double*)s.dev(H, Wf, 8) : nullptr;
+    if (s.rc) return s.rc;
+    if ((rc = gpt_gp_rfft2_vjp(c, dy, 0, dl, 0, dc, 0, dzb, 0, H, W, 1, dim1, dyb, dcb))) return rc;
+    s.down(ybar, dyb, H, W, 8);
+    if (covbar) s.down(covbar, dcb, H, Wf, 8);
+    return s.finish(nullptr);
+}
+
+static int spec_host(gpt_ctx* c, int layout, bool matern, double nu, int64_t H, int64_t W, const double* params,
+                     int dim1, double* out) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 3));
+    const double* dp = (const double*)s.up(params, 1, dim1 ? 3 : 5, 8);
+    double* dout = (double*)s.dev(H, Wf, 8);
+    if (s.rc) return s.rc;
+    rc = matern ? gpt_gp_periodic_matern_cov_rfft2(c, nu, H, W, dp, 1, dim1, dout)
+                : gpt_gp_periodic_exp_quad_cov_rfft2(c, H, W, dp, 1, dim1, dout);
+    if (rc) return rc;
+    s.down(out, dout, H, Wf, 8);
+    return s.finish(nullptr);
+}
+
+static int spec_vjp_host(gpt_ctx* c, int layout, bool matern, double nu, int64_t H, int64_t W,
+                         const double* params, const double* covbar, int dim1, double* params_bar) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 4));
+    const double* dp = (const double*)s.up(params, 1, dim1 ? 3 : 5, 8);
+    const double* dcb = (const double*)s.up(covbar, H, Wf, 8);
+    double* dpb = (double*)s.dev(1, 8, 8);
+    if (s.rc) return s.rc;
+    rc = matern ? gpt_gp_periodic_matern_cov_rfft2_vjp(c, nu, H, W, dp, dcb, 0, 1, dim1, dpb)
+                : gpt_gp_periodic_exp_quad_cov_rfft2_vjp(c, H, W, dp, dcb, 0, 1, dim1, dpb);
+    if (rc) return rc;
+    s.down(params_bar, dpb, 1, dim1 ? 3 : 5, 8);
+    return s.finish(nullptr);
+}
+
+int gpt_gp_periodic_exp_quad_cov_rfft2_host(gpt_ctx* c, int layout, int64_t H, int64_t W, const double* params,
+                                            int dim1, double* out) {
+    return spec_host(c, layout, false, 0.0, H, W, params, dim1, out);
+}
+int gpt_gp_periodic_matern_cov_rfft2_host(gpt_ctx* c, int layout, double nu, int64_t H, int64_t W,
+                                          const double* params, int dim1, double* out) {
+    return spec_host(c, layout, true, nu, H, W, params, dim1, out);
+}
+int gpt_gp_periodic_exp_quad_cov_rfft2_vjp_host(gpt_ctx* c, int layout, int64_t H, int64_t W,
+                                                const double* params, const double* covbar, int dim1,
+                                                double* params_bar) {
+    return spec_vjp_host(c, layout, false, 0.0, H, W, params, covbar, dim1, params_bar);
+}
+int gpt_gp_periodic_matern_cov_rfft2_vjp_host(gpt_ctx* c, int layout, double nu, int64_t H, int64_t W,
+                                              const double* params, const double* covbar, int dim1,
+                                              double* params_bar) {
+    return spec_vjp_host(c, layout, true, nu, H, W, params, covbar, dim1, params_bar);
+}
+
+} // extern "C"

@@ -1,0 +1,373 @@
+// Shared device-side definitions for the Fourier-GP kernels (gfx950 / MI355X only).
+//
+// Layout vocabulary (all fp64):
+//   lattice        H x W real field, row-major (torch / NumPy order); Stan's column-major matrices are
+//                  transposed by the host-pointer entry points before they get here.
+//   half spectrum  H x Wf complex, Wf = W/2 + 1: what the reference's rfft2 returns (util.stan:302-304).
+//   packed spectrum (internal workspace) H x NC complex, NC = 1 + (W-1)/2:
+//                  column 0 holds  A + i*B  where A is the (real-row-transform) DC column j = 0 and B the
+//                  Nyquist column j = W/2 (B = 0 when W is odd); columns 1..wc hold j = 1..wc as they are.
+//                  Both A and B are column transforms of real sequences, so they separate by Hermitian
+//                  symmetry: A[k] = (Z[k] + conj Z[H-k])/2, B[k] = (Z[k] - conj Z[H-k])/(2i).
+//                  This is exactly the set of entries fft2.stan:55-74 reads (rows 0..H/2 of the two edge
+//                  columns, all rows of the interior columns).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double2 cplx;
+
+#define GPT_MAX_STAGES 16
+
+enum GptOp : int {
+    OP_RFFT2 = 0,        // raw rfft2: real lattice -> half spectrum                       util.stan:302
+    OP_INV_RFFT2 = 1,    // raw inv_rfft2: half spectrum -> real lattice                   util.stan:315
+    OP_GP_RFFT2 = 2,     // z = unpack(rfft2(y-loc)/scale)                                fft2.stan:112
+    OP_GP_INV_RFFT2 = 3, // f = inv_rfft2(pack(z)*scale) + loc                            fft2.stan:126
+    OP_LPDF = 4,         // gp_rfft2_lpdf value only                                      fft2.stan:189
+    OP_LPDF_VJP = 5,     // value + d/dy + d/dcov (fused forward/backward)
+    OP_INV_VJP = 6,      // VJP of OP_GP_INV_RFFT2: fbar -> zbar, covbar
+    OP_FWD_VJP = 7,      // VJP of OP_GP_RFFT2: zbar -> ybar, covbar
+    OP_COUNT = 8
+};
+
+__host__ __device__ constexpr bool op_has_fwd(int op) {
+    return op == OP_RFFT2 || op == OP_GP_RFFT2 || op == OP_LPDF || op == OP_LPDF_VJP ||
+           op == OP_INV_VJP || op == OP_FWD_VJP;
+}
+__host__ __device__ constexpr bool op_has_inv(int op) {
+    return op == OP_INV_RFFT2 || op == OP_GP_INV_RFFT2 || op == OP_LPDF_VJP || op == OP_FWD_VJP;
+}
+
+// One line-FFT plan (any length): Stockham stages with radices r[0..ns).
+struct LinePlan {
+    int n;
+    int ns;
+    int r[GPT_MAX_STAGES];
+    const cplx* tw; // device table w_n^m = exp(-2 pi i m / n), m = 0..n-1
+};
+
+struct LatArgs {
+    int H, W;        // lattice shape (H = 1 for the 1-D functions)
+    int dim1;        // 1: 1-D packing layout of fft1.stan:44-51, 0: 2-D layout of fft2.stan:55-74
+    int64_t batch;
+    // real inputs (device pointers); *_bs = batch stride in elements (0 broadcasts)
+    const double* x;   // y (forward ops), z (OP_GP_INV_RFFT2 / OP_INV_VJP), y (OP_FWD_VJP)
+    const double* loc; // may be null (treated as 0)
+    const double* cov; // H x Wf
+    const double* aux; // fbar (OP_INV_VJP: transformed), zbar (OP_FWD_VJP)
+    const cplx* cin;   // complex half-spectrum input (OP_INV_RFFT2)
+    int64_t x_bs, loc_bs, cov_bs, aux_bs, cin_bs;
+    // outputs
+    double* out;      // H x W real per lattice
+    double* out_cov;  // H x Wf real per lattice (may be null)
+    cplx* out_c;      // H x Wf complex per lattice (OP_RFFT2)
+    double* out_lpdf; // [batch]
+    double* min_eig;  // [batch]: min over the whole H x Wf matrix of n*c/2 (may be null)
+    LinePlan pw, ph;  // line plans for length W and length H
+};
+
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ cplx cmulc(cplx a, cplx b) { // a * conj(b)
+    return make_double2(fma(a.x, b.x, a.y * b.y), fma(a.y, b.x, -a.x * b.y));
+}
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ cplx cscale(cplx a, double s) { return make_double2(a.x * s, a.y * s); }
+
+// 64-lane wavefront reductions (DPP/shuffle based), then one LDS hop across the waves of a workgroup.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// red must hold >= 2 * (blockDim.x / 64) doubles. Result valid in thread 0.
+__device__ __forceinline__ void block_sum_min(double& s, double& m, double* red) {
+    s = wave_sum(s);
+    m = wave_min(m);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) {
+        red[w] = s;
+        red[nw + w] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ss = 0.0, mm = INFINITY;
+        for (int i = 0; i < nw; ++i) {
+            ss += red[i];
+            mm = fmin(mm, red[nw + i]);
+        }
+        s = ss;
+        m = mm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Packing layout of the whitened coefficients z (the bit-exact contract of the reference).
+// 2-D (fft2.stan:55-74): column 0 <- edge column j=0; columns 1..wc <- Re of j=1..wc; columns
+//   1+wc..2wc <- Im of j=1..wc; (W even) column W-1 <- edge column j=W/2. Inside an edge column
+//   (fft1.stan:44-51 applied along the height): rows 0..H/2 <- Re of k, rows Hf..H-1 <- Im of k=1..hc.
+// 1-D (fft1.stan:44-51): [Re_0..Re_{n/2}, Im_1..Im_nc].
+struct ZLayout {
+    int H, W, Wf, Hf, wc, hc, dim1;
+    __device__ __forceinline__ int re_col(int j) const { // interior j in 1..wc
+        return j;
+    }
+    __device__ __forceinline__ int im_col(int j) const { return dim1 ? (Wf + j - 1) : (j + wc); }
+    // column of z that holds edge column j (j == 0 or j == W/2)
+    __device__ __forceinline__ int edge_col(int j) const { return j == 0 ? 0 : (dim1 ? W / 2 : W - 1); }
+};
+
+__device__ __forceinline__ ZLayout make_layout(const LatArgs& a) {
+    ZLayout L;
+    L.H = a.H;
+    L.W = a.W;
+    L.Wf = a.W / 2 + 1;
+    L.Hf = a.H / 2 + 1;
+    L.wc = (a.W - 1) / 2;
+    L.hc = (a.H - 1) / 2;
+    L.dim1 = a.dim1;
+    return L;
+}
+
+// Per-thread accumulators of the elementwise stage.
+struct EwAcc {
+    double sum; // log-density partial
+    double mn;  // min of n*c/2 seen
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Elementwise stage, INTERIOR entry (i, j), 1 <= j <= wc: a "complex pair" whose Re and Im are both
+// whitened with s^2 = n c / 2 (fft2.stan:13-40, 67-68). F is the spectrum value on entry (ops with a
+// forward transform); the return value replaces it (ops with an inverse transform).
+template <int OP>
+__device__ __forceinline__ cplx ew_interior(const LatArgs& a, const ZLayout& L, int64_t b, int i, int j,
+                                           cplx F, EwAcc& acc) {
+    const double n = (double)a.H * (double)a.W;
+    const int64_t hw = (int64_t)a.H * a.W, hwf = (int64_t)a.H * L.Wf;
+    cplx ret = F;
+    if (OP == OP_RFFT2) {
+        a.out_c[b * hwf + (int64_t)i * L.Wf + j] = F;
+        return ret;
+    }
+    if (OP == OP_INV_RFFT2) {
+        return a.cin[b * a.cin_bs + (int64_t)i * L.Wf + j];
+    }
+    const double c = a.cov[b * a.cov_bs + (int64_t)i * L.Wf + j];
+    acc.mn = fmin(acc.mn, 0.5 * n * c);
+    if (OP == OP_GP_RFFT2) {
+        const double inv_s = 1.0 / sqrt(0.5 * n * c);
+        double* o = a.out + b * hw + (int64_t)i * a.W;
+        o[L.re_col(j)] = F.x * inv_s;
+        o[L.im_col(j)] = F.y * inv_s;
+    } else if (OP == OP_GP_INV_RFFT2) {
+        const double s = sqrt(0.5 * n * c);
+        const double* z = a.x + b * a.x_bs + (int64_t)i * a.W;
+        ret = make_double2(z[L.re_col(j)] * s, z[L.im_col(j)] * s);
+    } else if (OP == OP_LPDF || OP == OP_LPDF_VJP) {
+        const double f2 = fma(F.x, F.x, F.y * F.y);
+        const double inv_c = 1.0 / c;
+        const double q = f2 * inv_c / n; // |F|^2 / (n c)
+        acc.sum -= q + log(c);
+        if (OP == OP_LPDF_VJP) {
+            if (a.out_cov) a.out_cov[b * hwf + (int64_t)i * L.Wf + j] = (q - 1.0) * inv_c;
+            ret = cscale(F, inv_c);
+        }
+    } else if (OP == OP_INV_VJP) {
+        // F = R = rfft2(fbar); P = pack(z)
+        const double s = sqrt(0.5 * n * c);
+        const double* z = a.x + b * a.x_bs + (int64_t)i * a.W;
+        const double pr = z[L.re_col(j)], pi = z[L.im_col(j)];
+        double* o = a.out + b * hw + (int64_t)i * a.W;
+        const double k2 = 2.0 / n;
+        o[L.re_col(j)] = k2 * s * F.x;
+        o[L.im_col(j)] = k2 * s * F.y;
+        if (a.out_cov) {
+            const double sbar = k2 * fma(pr, F.x, pi * F.y);
+            a.out_cov[b * hwf + (int64_t)i * L.Wf + j] = sbar * s / (2.0 * c);
+        }
+    } else if (OP == OP_FWD_VJP) {
+        // F = rfft2(y - loc); Q = pack(zbar); returns Dh = Q / (2 s)
+        const double s = sqrt(0.5 * n * c);
+        const double* zb = a.aux + b * a.aux_bs + (int64_t)i * a.W;
+        const double qr = zb[L.re_col(j)], qi = zb[L.im_col(j)];
+        if (a.out_cov)
+            a.out_cov[b * hwf + (int64_t)i * L.Wf + j] = -fma(qr, F.x, qi * F.y) / (2.0 * c * s);
+        ret = make_double2(0.5 * qr / s, 0.5 * qi / s);
+    }
+    return ret;
+}
+
+// Elementwise stage, EDGE column j (j == 0 or, W even, j == W/2), row k in 0..H/2. FA is the value of
+// that column's own transform at row k (already separated from the packed column). Rows k = 0 and
+// (H even) k = H/2 are "real points" (only Re is whitened, s^2 = n c); rows 1..hc are complex pairs whose
+// mirror row H-k is never read by the reference in the forward direction (fft2.stan:65,71), but whose
+// scale IS used, row by row, in the inverse direction (fft2.stan:127-128).
+// Returns the replacement value at row k; the caller mirrors it (conj) to row H-k.
+template <int OP>
+__device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, int64_t b, int k, int j, cplx FA,
+                                       EwAcc& acc) {
+    const double n = (double)a.H * (double)a.W;
+    const int64_t hw = (int64_t)a.H * a.W, hwf = (int64_t)a.H * L.Wf;
+    const bool real_pt = (k == 0) || (2 * k == a.H);
+    const int km = real_pt ? k : a.H - k; // mirror row
+    cplx ret = FA;
+    if (OP == OP_RFFT2) {
+        cplx* o = a.out_c + b * hwf;
+        if (real_pt) {
+            o[(int64_t)k * L.Wf + j] = make_double2(FA.x, 0.0);
+        } else {
+            o[(int64_t)k * L.Wf + j] = FA;
+            o[(int64_t)km * L.Wf + j] = cconj(FA);
+        }
+        return ret;
+    }
+    if (OP == OP_INV_RFFT2) {
+        // the real part of inv_fft2 keeps the Hermitian part of the column only (util.stan:329)
+        const cplx* zi = a.cin + b * a.cin_bs;
+        const cplx u = zi[(int64_t)k * L.Wf + j];
+        if (real_pt) return make_double2(u.x, 0.0);
+        const cplx v = zi[(int64_t)km * L.Wf + j];
+        return make_double2(0.5 * (u.x + v.x), 0.5 * (u.y - v.y));
+    }
+    const double* cb = a.cov + b * a.cov_bs;
+    const double c = cb[(int64_t)k * L.Wf + j];
+    const double cm = real_pt ? c : cb[(int64_t)km * L.Wf + j];
+    acc.mn = fmin(acc.mn, 0.5 * n * fmin(c, cm));
+    const int jz = L.edge_col(j);
+    // position of Re/Im of row k inside the packed z column (fft1.stan:44-51 along the height);
+    // for the 1-D functions H == 1 and only k == 0 exists.
+    if (OP == OP_GP_RFFT2) {
+        double* o = a.out + b * hw;
+        if (real_pt) {
+            o[(int64_t)k * a.W + jz] = FA.x / sqrt(n * c);
+        } else {
+            const double inv_s = 1.0 / sqrt(0.5 * n * c);
+            o[(int64_t)k * a.W + jz] = FA.x * inv_s;
+            o[(int64_t)(L.Hf + k - 1) * a.W + jz] = FA.y * inv_s;
+        }
+    } else if (OP == OP_GP_INV_RFFT2) {
+        const double* z = a.x + b * a.x_bs;
+        if (real_pt) {
+            ret = make_double2(z[(int64_t)k * a.W + jz] * sqrt(n * c), 0.0);
+        } else {
+            const double se = 0.5 * (sqrt(0.5 * n * c) + sqrt(0.5 * n * cm));
+            ret = make_double2(z[(int64_t)k * a.W + jz] * se, z[(int64_t)(L.Hf + k - 1) * a.W + jz] * se);
+        }
+    } else if (OP == OP_LPDF || OP == OP_LPDF_VJP) {
+        const double inv_c = 1.0 / c;
+        if (real_pt) {
+            const double q = FA.x * FA.x * inv_c / n;
+            acc.sum -= 0.5 * (q + log(c));
+            if (OP == OP_LPDF_VJP) {
+                if (a.out_cov) a.out_cov[b * hwf + (int64_t)k * L.Wf + j] = 0.5 * (q - 1.0) * inv_c;
+                ret = make_double2(FA.x * inv_c, 0.0);
+            }
+        } else {
+            const double q = fma(FA.x, FA.x, FA.y * FA.y) * inv_c / n;
+            acc.sum -= q + log(c);
+            if (OP == OP_LPDF_VJP) {
+                if (a.out_cov) {
+                    a.out_cov[b * hwf + (int64_t)k * L.Wf + j] = (q - 1.0) * inv_c;
+                    a.out_cov[b * hwf + (int64_t)km * L.Wf + j] = 0.0;
+                }
+                ret = cscale(FA, inv_c);
+            }
+        }
+    } else if (OP == OP_INV_VJP) {
+        const double* z = a.x + b * a.x_bs;
+        double* o = a.out + b * hw;
+        const double k1 = 1.0 / n;
+        if (real_pt) {
+            const double s = sqrt(n * c);
+            o[(int64_t)k * a.W + jz] = k1 * s * FA.x;
+            if (a.out_cov) {
+                const double sbar = k1 * z[(int64_t)k * a.W + jz] * FA.x;
+                a.out_cov[b * hwf + (int64_t)k * L.Wf + j] = sbar * s / (2.0 * c);
+            }
+        } else {
+            const double s = sqrt(0.5 * n * c), sm = sqrt(0.5 * n * cm);
+            const double pr = z[(int64_t)k * a.W + jz], pi = z[(int64_t)(L.Hf + k - 1) * a.W + jz];
+            o[(int64_t)k * a.W + jz] = k1 * (s + sm) * FA.x;
+            o[(int64_t)(L.Hf + k - 1) * a.W + jz] = k1 * (s + sm) * FA.y;
+            if (a.out_cov) {
+                const double sbar = k1 * fma(pr, FA.x, pi * FA.y);
+                a.out_cov[b * hwf + (int64_t)k * L.Wf + j] = sbar * s / (2.0 * c);
+                a.out_cov[b * hwf + (int64_t)km * L.Wf + j] = sbar * sm / (2.0 * cm);
+            }
+        }
+    } else if (OP == OP_FWD_VJP) {
+        const double* zb = a.aux + b * a.aux_bs;
+        if (real_pt) {
+            const double s = sqrt(n * c);
+            const double qr = zb[(int64_t)k * a.W + jz];
+            if (a.out_cov) a.out_cov[b * hwf + (int64_t)k * L.Wf + j] = -(qr * FA.x) / (2.0 * c * s);
+            ret = make_double2(qr / s, 0.0);
+        } else {
+            const double s = sqrt(0.5 * n * c);
+            const double qr = zb[(int64_t)k * a.W + jz], qi = zb[(int64_t)(L.Hf + k - 1) * a.W + jz];
+            if (a.out_cov) {
+                a.out_cov[b * hwf + (int64_t)k * L.Wf + j] = -fma(qr, FA.x, qi * FA.y) / (2.0 * c * s);
+                a.out_cov[b * hwf + (int64_t)km * L.Wf + j] = 0.0;
+            }
+            ret = make_double2(0.5 * qr / s, 0.5 * qi / s);
+        }
+    }
+    return ret;
+}
+
+// Elementwise stage on the packed column 0 at row k in 0..H/2: Zk = Z[k], Zm = Z[(H-k)%H] on entry
+// (forward ops) and on exit (inverse ops). Splits into the two edge columns, applies ew_edge, recombines.
+template <int OP>
+__device__ __forceinline__ void ew_packed0(const LatArgs& a, const ZLayout& L, int64_t b, int k, cplx& Zk,
+                                           cplx& Zm, EwAcc& acc) {
+    const bool weven = (a.W % 2) == 0;
+    // A = (Zk + conj Zm)/2 ; B = (Zk - conj Zm)/(2i)
+    cplx A = make_double2(0.5 * (Zk.x + Zm.x), 0.5 * (Zk.y - Zm.y));
+    cplx B = make_double2(0.5 * (Zk.y + Zm.y), -0.5 * (Zk.x - Zm.x));
+    A = ew_edge<OP>(a, L, b, k, 0, A, acc);
+    if (weven) B = ew_edge<OP>(a, L, b, k, a.W / 2, B, acc);
+    else B = make_double2(0.0, 0.0);
+    if (op_has_inv(OP)) {
+        // Z[k] = A + iB ; Z[H-k] = conj(A) + i conj(B)
+        Zk = make_double2(A.x - B.y, A.y + B.x);
+        Zm = make_double2(A.x + B.y, -A.y + B.x);
+    }
+}
+
+// Output transform of the final (real) stage.
+//   OP_INV_RFFT2:    out = v / n
+//   OP_GP_INV_RFFT2: out = v / n + loc
+//   OP_LPDF_VJP:     out = -v / n            (d lpdf / d y)
+//   OP_FWD_VJP:      out = v                 (the 1/2 weights already carry the n)
+template <int OP>
+__device__ __forceinline__ double out_transform(const LatArgs& a, int64_t b, int i, int j, double v) {
+    const double n = (double)a.H * (double)a.W;
+    if (OP == OP_INV_RFFT2) return v / n;
+    if (OP == OP_GP_INV_RFFT2) {
+        const double l = a.loc ? a.loc[b * a.loc_bs + (int64_t)i * a.W + j] : 0.0;
+        return v / n + l;
+    }
+    if (OP == OP_LPDF_VJP) return -v / n;
+    return v;
+}
+
+// Input transform of the first (real) stage.
+template <int OP>
+__device__ __forceinline__ double in_transform(const LatArgs& a, int64_t b, int i, int j) {
+    const int64_t off = (int64_t)i * a.W + j;
+    if (OP == OP_INV_VJP) return a.aux[b * a.aux_bs + off]; // fbar
+    const double v = a.x[b * a.x_bs + off];
+    if (OP == OP_RFFT2) return v;
+    return a.loc ? v - a.loc[b * a.loc_bs + off] : v;
+}

@@ -1,0 +1,59 @@
+// Host-side declarations shared by the translation units of libgptools_hip.so (internal; the public C
+// ABI is include/gptools_hip.h).
+#pragma once
+#include "gpt_common.h"
+
+// --- small-lattice path (gpt_small.hip)
+bool gpt_small_fits(int H, int W, int* cap_out, int* stride_out);
+hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st);
+
+// --- large power-of-two path (gpt_pow2.hip)
+// Workspace: packed spectrum, (H * (W/2 + GPT_WS_PAD)) complex per lattice processed concurrently.
+#define GPT_WS_PAD 8
+bool gpt_pow2_supported(int H, int W);
+size_t gpt_pow2_workspace_bytes(int H, int W);
+int gpt_pow2_col_blocks(int H, int W);
+hipError_t gpt_launch_pow2(int op, const LatArgs& a, cplx* ws, double* partials, hipStream_t st);
+
+// --- generic large path (gpt_generic.hip): any H, W whose lines fit LDS
+bool gpt_generic_supported(int H, int W);
+size_t gpt_generic_workspace_bytes(int H, int W);
+int gpt_generic_col_blocks(int H, int W);
+hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partials, hipStream_t st);
+
+// --- elementwise / reduction kernels (gpt_elem.hip)
+struct ElemArgs {
+    int H, W, dim1;
+    int64_t batch;
+    const double* in;  // real input
+    const cplx* cin;   // complex input
+    const double* par; // kernel parameters [batch][5] (2-D: sigma, l1, l2, p1, p2) or [batch][3] (1-D)
+    int64_t in_bs, cin_bs;
+    double* out;
+    cplx* cout;
+    double* min_eig;
+    double nu, gamma_ratio; // Matern smoothness and tgamma(nu + ndim/2) / tgamma(nu)
+};
+enum ElemOp : int {
+    EL_SCALE = 0,      // gp_evaluate_rfft(2)_scale
+    EL_UNPACK = 1,     // gp_unpack_rfft(2)
+    EL_PACK = 2,       // gp_pack_rfft(2)
+    EL_LADJ = 3,       // gp_rfft(2)_log_abs_det_jac
+    EL_LADJ_VJP = 4,   // its gradient w.r.t. cov
+    EL_EXPQUAD = 5,    // gp_periodic_exp_quad_cov_rfft(2)
+    EL_MATERN = 6,     // gp_periodic_matern_cov_rfft(2)
+    EL_EXPQUAD_VJP = 7,
+    EL_MATERN_VJP = 8,
+    EL_EXPAND = 9      // expand_rfft
+};
+// `partials` must hold batch * gpt_elem_blocks(H, W) * 8 doubles for the reducing ops.
+int gpt_elem_blocks(int H, int W);
+hipError_t gpt_launch_elem(int op, const ElemArgs& e, double* partials, hipStream_t st);
+// Second (atomic-free) reduction stage. `partials` is [batch][nblk][GPT_PART] doubles: slots 0..4 are
+// sums, slot 5 a minimum. Emits out_sum[b * K + k] = sum_k (+ add for k == 0) for k < K (if out_sum) and
+// out_min[b] (if out_min).
+#define GPT_PART 8
+hipError_t gpt_launch_finalize(const double* partials, int nblk, int64_t batch, int K, double add,
+                               double* out_sum, double* out_min, hipStream_t st);
+// Row-major <-> column-major (Stan/Eigen) transposes of a batch of R x C matrices of `esz`-byte elements.
+hipError_t gpt_launch_transpose(const void* in, void* out, int R, int C, int64_t batch, int esz, hipStream_t st);

@@ -1,0 +1,170 @@
+/*
+ * gptools_hip.h -- C ABI of libgptools_hip.so: the Fourier-method Gaussian-process path of
+ * onnela-lab/gptools as hand-written HIP kernels for AMD MI355X (gfx950).
+ *
+ * Every entry point replaces one function of the reference's Stan library (cited as file:line relative
+ * to the reference checkout) or is the reverse-mode derivative Stan's autodiff would have produced for it.
+ *
+ * Conventions
+ *   - all data are IEEE fp64; complex values are interleaved (re, im) pairs (std::complex<double>);
+ *   - sizes are int64_t (`height`, `width`, `n`), `batch` >= 0 lattices are evaluated per call;
+ *   - the 1-D functions are the 2-D ones with height == 1 and the 1-D packing layout of fft1.stan:44-51;
+ *   - gpt_*        : every pointer is a DEVICE pointer, arrays are row-major (NumPy / torch order), the
+ *                    call is asynchronous on the context's stream and never allocates in the steady
+ *                    state (workspaces are cached in the context). `*_bs` arguments are batch strides in
+ *                    elements; 0 broadcasts one array over the batch. Output arrays are dense
+ *                    ([batch][height][width] etc.).
+ *   - gpt_*_host   : every pointer is a HOST pointer; the library stages H2D/D2H, synchronises, and
+ *                    applies the reference's `reject` checks. `layout` selects GPT_COL_MAJOR (Stan /
+ *                    Eigen matrices) or GPT_ROW_MAJOR.
+ *   - return value : GPT_OK, or
+ *         GPT_ERR_NOT_PD      (host entry points only) the reference would `reject` with "covariance matrix
+ *                             is not positive-definite (minimum eigenvalue is <v>)" (fft1.stan:19-21,
+ *                             fft2.stan:21-23); <v> is returned by gpt_last_min_eig(). Device entry
+ *                             points report it through their `min_eig` output instead (min over the whole
+ *                             matrix of n*c/2, per lattice; reject iff < 0) so that they stay asynchronous.
+ *         GPT_ERR_SHAPE       sizes that the reference rejects or cannot represent (util.stan:274-276);
+ *         GPT_ERR_UNSUPPORTED a lattice shape this build has no kernel for (message says which);
+ *         GPT_ERR_HIP / GPT_ERR_ALLOC  a HIP failure; gpt_last_error() has the text.
+ *     The library never aborts or exits.
+ *   - threading    : a context is owned by one thread at a time; use one context per calling thread
+ *                    (cmdstan chains are processes or STAN_THREADS threads). Several processes may share
+ *                    a GPU.
+ */
+#ifndef GPTOOLS_HIP_H
+#define GPTOOLS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpt_ctx gpt_ctx;
+
+enum {
+    GPT_OK = 0,
+    GPT_ERR_NOT_PD = 1,
+    GPT_ERR_SHAPE = 2,
+    GPT_ERR_UNSUPPORTED = 3,
+    GPT_ERR_HIP = -1,
+    GPT_ERR_ALLOC = -2
+};
+enum { GPT_ROW_MAJOR = 0, GPT_COL_MAJOR = 1 };
+
+/* ---- context ------------------------------------------------------------------------------------- */
+/* `stream` is a hipStream_t the caller owns (NULL: HIP's default stream). */
+int gpt_create(int device, void* stream, gpt_ctx** out);
+int gpt_destroy(gpt_ctx* ctx);
+int gpt_set_stream(gpt_ctx* ctx, void* stream);
+int gpt_synchronize(gpt_ctx* ctx);
+const char* gpt_last_error(const gpt_ctx* ctx);
+double gpt_last_min_eig(const gpt_ctx* ctx);
+const char* gpt_version(void);
+/* Which kernel family a lattice shape runs on: 0 small (one workgroup per lattice, any H/W),
+ * 1 power-of-two three-pass, 2 generic three-pass, -1 unsupported. */
+int gpt_path_for_shape(int64_t height, int64_t width);
+
+/* ---- real-FFT layer: stan/gptools/util.stan:255-330 ------------------------------------------------ */
+/* rfft2 (util.stan:302-304): y[batch][H][W] -> out[batch][H][W/2+1] complex.  rfft (util.stan:263-265) is
+ * the height == 1 case. */
+int gpt_rfft2(gpt_ctx*, const double* y, int64_t height, int64_t width, int64_t batch, double* out_complex);
+/* inv_rfft2 (util.stan:315-330): z[batch][H][W/2+1] complex -> out[batch][H][W]; inv_rfft
+ * (util.stan:291-293) is the height == 1 case. */
+int gpt_inv_rfft2(gpt_ctx*, const double* z_complex, int64_t height, int64_t width, int64_t batch, double* out);
+/* expand_rfft (util.stan:271-281): y[batch][n/2+1] complex -> out[batch][n] complex. */
+int gpt_expand_rfft(gpt_ctx*, const double* y_complex, int64_t n, int64_t batch, double* out_complex);
+
+/* ---- GP layer: stan/gptools/fft1.stan, fft2.stan ---------------------------------------------------
+ * `dim1` != 0 selects the 1-D functions (height must be 1; layout of fft1.stan:44-51). */
+
+/* gp_evaluate_rfft_scale (fft1.stan:14-30) / gp_evaluate_rfft2_scale (fft2.stan:13-40) */
+int gpt_gp_evaluate_rfft2_scale(gpt_ctx*, const double* cov, int64_t cov_bs, int64_t height, int64_t width,
+                                int64_t batch, int dim1, double* out, double* min_eig);
+/* gp_unpack_rfft (fft1.stan:44-51) / gp_unpack_rfft2 (fft2.stan:55-74) */
+int gpt_gp_unpack_rfft2(gpt_ctx*, const double* z_complex, int64_t height, int64_t width, int64_t batch,
+                        int dim1, double* out);
+/* gp_pack_rfft (fft1.stan:108-118) / gp_pack_rfft2 (fft2.stan:85-100) */
+int gpt_gp_pack_rfft2(gpt_ctx*, const double* z, int64_t height, int64_t width, int64_t batch, int dim1,
+                      double* out_complex);
+/* gp_rfft (fft1.stan:64-66) / gp_rfft2 (fft2.stan:112-114): z = unpack(rfft2(y - loc) ./ scale) */
+int gpt_gp_rfft2(gpt_ctx*, const double* y, int64_t y_bs, const double* loc, int64_t loc_bs, const double* cov,
+                 int64_t cov_bs, int64_t height, int64_t width, int64_t batch, int dim1, double* z_out,
+                 double* min_eig);
+/* gp_inv_rfft (fft1.stan:139-143) / gp_inv_rfft2 (fft2.stan:126-130) */
+int gpt_gp_inv_rfft2(gpt_ctx*, const double* z, int64_t z_bs, const double* loc, int64_t loc_bs,
+                     const double* cov, int64_t cov_bs, int64_t height, int64_t width, int64_t batch, int dim1,
+                     double* f_out, double* min_eig);
+/* gp_rfft_log_abs_det_jac (fft1.stan:78-82) / gp_rfft2_log_abs_det_jac (fft2.stan:143-173) */
+int gpt_gp_rfft2_log_abs_det_jac(gpt_ctx*, const double* cov, int64_t cov_bs, int64_t height, int64_t width,
+                                 int64_t batch, int dim1, double* out, double* min_eig);
+/* its gradient w.r.t. cov (reverse mode of the function above; no reference code: Stan autodiff) */
+int gpt_gp_rfft2_log_abs_det_jac_vjp(gpt_ctx*, const double* cov, int64_t cov_bs, int64_t height,
+                                     int64_t width, int64_t batch, int dim1, double* grad_cov);
+/* gp_rfft_lpdf (fft1.stan:96-101) / gp_rfft2_lpdf (fft2.stan:189-192): value only */
+int gpt_gp_rfft2_lpdf(gpt_ctx*, const double* y, int64_t y_bs, const double* loc, int64_t loc_bs,
+                      const double* cov, int64_t cov_bs, int64_t height, int64_t width, int64_t batch, int dim1,
+                      double* lpdf, double* min_eig);
+/* Fused value + gradients of the function above (the hot path): grad_y[batch][H][W] = d lpdf / d y
+ * (d lpdf / d loc = -grad_y), grad_cov[batch][H][W/2+1] (may be NULL). */
+int gpt_gp_rfft2_lpdf_vjp(gpt_ctx*, const double* y, int64_t y_bs, const double* loc, int64_t loc_bs,
+                          const double* cov, int64_t cov_bs, int64_t height, int64_t width, int64_t batch,
+                          int dim1, double* lpdf, double* grad_y, double* grad_cov, double* min_eig);
+/* Reverse mode of gp_inv_rfft(2): fbar[batch][H][W] -> zbar[batch][H][W], covbar[batch][H][W/2+1] (may be
+ * NULL); d/dloc = fbar. */
+int gpt_gp_inv_rfft2_vjp(gpt_ctx*, const double* z, int64_t z_bs, const double* cov, int64_t cov_bs,
+                         const double* fbar, int64_t fbar_bs, int64_t height, int64_t width, int64_t batch,
+                         int dim1, double* zbar, double* covbar);
+/* Reverse mode of gp_rfft(2): zbar -> ybar (d/dloc = -ybar), covbar (may be NULL). */
+int gpt_gp_rfft2_vjp(gpt_ctx*, const double* y, int64_t y_bs, const double* loc, int64_t loc_bs,
+                     const double* cov, int64_t cov_bs, const double* zbar, int64_t zbar_bs, int64_t height,
+                     int64_t width, int64_t batch, int dim1, double* ybar, double* covbar);
+
+/* Spectral kernels. `params` is [batch][5] = (sigma, length_scale[0], length_scale[1], period[0],
+ * period[1]) for the 2-D functions and [batch][3] = (sigma, length_scale, period) for the 1-D ones.
+ * gp_periodic_exp_quad_cov_rfft (fft1.stan:154-158) / _rfft2 (fft2.stan:206-213) */
+int gpt_gp_periodic_exp_quad_cov_rfft2(gpt_ctx*, int64_t height, int64_t width, const double* params,
+                                       int64_t batch, int dim1, double* out);
+/* gp_periodic_matern_cov_rfft (fft1.stan:170-176) / _rfft2 (fft2.stan:228-247) */
+int gpt_gp_periodic_matern_cov_rfft2(gpt_ctx*, double nu, int64_t height, int64_t width, const double* params,
+                                     int64_t batch, int dim1, double* out);
+/* Reverse mode: covbar[batch][H][W/2+1] -> params_bar[batch][5] (or [3]); nu is data (no d/dnu). */
+int gpt_gp_periodic_exp_quad_cov_rfft2_vjp(gpt_ctx*, int64_t height, int64_t width, const double* params,
+                                           const double* covbar, int64_t covbar_bs, int64_t batch, int dim1,
+                                           double* params_bar);
+int gpt_gp_periodic_matern_cov_rfft2_vjp(gpt_ctx*, double nu, int64_t height, int64_t width,
+                                         const double* params, const double* covbar, int64_t covbar_bs,
+                                         int64_t batch, int dim1, double* params_bar);
+
+/* ---- host-pointer entry points (what the Stan user header binds) ----------------
+ * One lattice per call (batch == 1), `layout` as above. Matrices are height x width (cov: height x
+ * (width/2+1)). */
+int gpt_gp_rfft2_host(gpt_ctx*, int layout, const double* y, const double* loc, const double* cov,
+                      int64_t height, int64_t width, int dim1, double* z_out);
+int gpt_gp_inv_rfft2_host(gpt_ctx*, int layout, const double* z, const double* loc, const double* cov,
+                          int64_t height, int64_t width, int dim1, double* f_out);
+int gpt_gp_rfft2_log_abs_det_jac_host(gpt_ctx*, int layout, const double* cov, int64_t height, int64_t width,
+                                      int dim1, double* out, double* grad_cov /* may be NULL */);
+int gpt_gp_rfft2_lpdf_host(gpt_ctx*, int layout, const double* y, const double* loc, const double* cov,
+                           int64_t height, int64_t width, int dim1, double* lpdf,
+                           double* grad_y /* may be NULL: value only */, double* grad_cov /* may be NULL */);
+int gpt_gp_inv_rfft2_vjp_host(gpt_ctx*, int layout, const double* z, const double* cov, const double* fbar,
+                              int64_t height, int64_t width, int dim1, double* zbar, double* covbar);
+int gpt_gp_rfft2_vjp_host(gpt_ctx*, int layout, const double* y, const double* loc, const double* cov,
+                          const double* zbar, int64_t height, int64_t width, int dim1, double* ybar,
+                          double* covbar);
+int gpt_gp_periodic_exp_quad_cov_rfft2_host(gpt_ctx*, int layout, int64_t height, int64_t width,
+                                            const double* params, int dim1, double* out);
+int gpt_gp_periodic_matern_cov_rfft2_host(gpt_ctx*, int layout, double nu, int64_t height, int64_t width,
+                                          const double* params, int dim1, double* out);
+int gpt_gp_periodic_exp_quad_cov_rfft2_vjp_host(gpt_ctx*, int layout, int64_t height, int64_t width,
+                                                const double* params, const double* covbar, int dim1,
+                                                double* params_bar);
+int gpt_gp_periodic_matern_cov_rfft2_vjp_host(gpt_ctx*, int layout, double nu, int64_t height, int64_t width,
+                                              const double* params, const double* covbar, int dim1,
+                                              double* params_bar);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPTOOLS_HIP_H */
