@@ -91,7 +91,7 @@ def _p(t):
 
 def _dev(x, like=None):
     if not isinstance(x, torch.Tensor):
-        x = torch.as_tensor(x, dtype=torch.float64)
+        x = torch.as_tensor(x)
     if x.dtype not in (torch.float64, torch.complex128):
         x = x.to(torch.complex128 if x.is_complex() else torch.float64)
     if not x.is_cuda:
@@ -153,14 +153,14 @@ def _prep(main, loc, cov, dim1):
 
 
 def _new(g, *shape):
-    return torch.empty(*g["bshape"], *shape, dtype=torch.float64, device=g["main"].device)
+    return torch.empty((*g["bshape"], *shape), dtype=torch.float64, device=g["main"].device)
 
 
 # ---- real-FFT layer: util.stan:255-330 -------------------------------------------------------------
 def rfft2(y):
     """util.stan:302-304."""
     g = _prep(y, None, None, False)
-    out = torch.empty(*g["bshape"], g["H"], g["Wf"], dtype=torch.complex128, device=g["main"].device)
+    out = torch.empty((*g["bshape"], g["H"], g["Wf"]), dtype=torch.complex128, device=g["main"].device)
     get_context(out.device).call("gpt_rfft2", _p(g["main"]), g["H"], g["W"], g["B"], _p(out))
     return out
 
@@ -178,7 +178,7 @@ def inv_rfft2(z, m):
     if Wf != m // 2 + 1:
         raise ValueError(f"expected complex matrix with {m // 2 + 1} columns but got {Wf}")
     bshape = tuple(z.shape[:-2])
-    out = torch.empty(*bshape, H, m, dtype=torch.float64, device=z.device)
+    out = torch.empty((*bshape, H, m), dtype=torch.float64, device=z.device)
     get_context(z.device).call("gpt_inv_rfft2", _p(z), H, m, _numel(bshape), _p(out))
     return out
 
@@ -195,7 +195,7 @@ def expand_rfft(y, n):
     if y.shape[-1] != n // 2 + 1:
         raise ValueError(f"expected complex vector with {n // 2 + 1} elements but got {y.shape[-1]}")
     bshape = tuple(y.shape[:-1])
-    out = torch.empty(*bshape, n, dtype=torch.complex128, device=y.device)
+    out = torch.empty((*bshape, n), dtype=torch.complex128, device=y.device)
     get_context(y.device).call("gpt_expand_rfft", _p(y), n, _numel(bshape), _p(out))
     return out
 
@@ -231,7 +231,7 @@ def _unpack(z, width, dim1):
     z = _dev(z).to(torch.complex128).contiguous()
     H = 1 if dim1 else z.shape[-2]
     bshape = tuple(z.shape[: -1 if dim1 else -2])
-    out = torch.empty(*bshape, *((width,) if dim1 else (H, width)), dtype=torch.float64, device=z.device)
+    out = torch.empty((*bshape, *((width,) if dim1 else (H, width))), dtype=torch.float64, device=z.device)
     get_context(z.device).call("gpt_gp_unpack_rfft2", _p(z), H, width, _numel(bshape), int(dim1), _p(out))
     return out
 
@@ -251,7 +251,7 @@ def _pack(z, dim1):
     W = z.shape[-1]
     H = 1 if dim1 else z.shape[-2]
     bshape = tuple(z.shape[: -1 if dim1 else -2])
-    out = torch.empty(*bshape, *((W // 2 + 1,) if dim1 else (H, W // 2 + 1)), dtype=torch.complex128,
+    out = torch.empty((*bshape, *((W // 2 + 1,) if dim1 else (H, W // 2 + 1))), dtype=torch.complex128,
                       device=z.device)
     get_context(z.device).call("gpt_gp_pack_rfft2", _p(z), H, W, _numel(bshape), int(dim1), _p(out))
     return out
@@ -448,7 +448,7 @@ def _params(dim1, sigma, length_scale, period, device=None):
 def _spec(kind, nu, height, width, sigma, length_scale, period, dim1):
     par, bshape = _params(dim1, sigma, length_scale, period)
     Wf = width // 2 + 1
-    out = torch.empty(*bshape, *((Wf,) if dim1 else (height, Wf)), dtype=torch.float64, device=par.device)
+    out = torch.empty((*bshape, *((Wf,) if dim1 else (height, Wf))), dtype=torch.float64, device=par.device)
     ctx = get_context(par.device)
     if kind == "expquad":
         ctx.call("gpt_gp_periodic_exp_quad_cov_rfft2", height, width, _p(par), _numel(bshape), int(dim1), _p(out))
@@ -483,7 +483,7 @@ def _spec_vjp(kind, nu, height, width, sigma, length_scale, period, covbar, dim1
     cb = _dev(covbar, par)
     cb, _, cb_bs = _batched(cb, 1 if dim1 else 2, bshape)
     npar = 3 if dim1 else 5
-    out = torch.empty(*bshape, npar, dtype=torch.float64, device=par.device)
+    out = torch.empty((*bshape, npar), dtype=torch.float64, device=par.device)
     ctx = get_context(par.device)
     if kind == "expquad":
         ctx.call("gpt_gp_periodic_exp_quad_cov_rfft2_vjp", height, width, _p(par), _p(cb), cb_bs, _numel(bshape),
