@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""
+Benchmark of the hot path: batched gp_rfft2_lpdf + gradients (fp64) on synthetic 4096 x 4096 lattices.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size S]
+
+A "step" is one call of the fused value+gradient entry point (gpt_gp_rfft2_lpdf_vjp through the C ABI)
+over a batch of B lattices that are already resident in HBM. With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank evaluates its own B lattices -- independent chains, no
+data-path collective -- so the scaling is weak and `value` is the whole-job rate.
+
+Prints ONE JSON line (rank 0). `roofline` prices the three-pass pipeline against the algorithmic bytes of
+the operator (24 n + 16 H (W/2+1) bytes per evaluation) using pass durations
+measured with HIP events inside the library (gpt_profile_begin/end), and lists every pass with its own
+compulsory bytes so the numbers can be held against the rocprofv3 summary under profiles/.
+`cpu_baseline` times the CPU oracle (oracle/gp_oracle.py, NumPy restatement of the reference) on the host
+cores of the same box, rank 0 and N == 1 only, on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def synthetic(fft, size, batch, device, seed):
+    """SURVEY 8(d) recipe: Matern-3/2 spectrum + nugget, y = gp_inv_rfft2(z, loc, c) with z ~ N(0, 1)."""
+    h = w = size
+    cov = fft.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.3, [8.0, 12.0], [float(h), float(w)]) + 1e-3
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    loc = torch.randn(h, w, dtype=torch.float64, device=device, generator=g)
+    g.manual_seed(20250321 + seed)
+    z = torch.randn(batch, h, w, dtype=torch.float64, device=device, generator=g)
+    y = fft.gp_inv_rfft2(z, loc, cov)
+    del z
+    return y, loc, cov
+
+
+def cpu_baseline(size, budget_s=20.0):
+    """Oracle (NumPy port of the reference maths, 1 core) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gp_oracle as oracle
+
+    rng = np.random.default_rng(0)
+    h = w = size
+    cov = oracle.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.3, [8.0, 12.0], [float(h), float(w)]) + 1e-3
+    loc = rng.normal(size=(h, w))
+    y = rng.normal(size=(h, w))
+    n_done, t0 = 0, time.perf_counter()
+    while True:
+        oracle.gp_rfft2_lpdf_vjp(y, loc, cov)
+        n_done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n_done >= 8:
+            break
+    return {
+        "value": n_done / el,
+        "unit": "evals/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n_done} evaluations of gp_rfft2_lpdf+grad at {size}x{size} with oracle/gp_oracle.py "
+                  f"(NumPy pocketfft, single thread) in {el:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="lattices per GPU per step")
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-pass HIP-event timing")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    from gptools_amd import fft
+
+    size, B = args.size, args.batch
+    h = w = size
+    n = h * w
+    hwf = h * (w // 2 + 1)
+    y, loc, cov = synthetic(fft, size, B, device, seed=rank)
+    lp = torch.empty(B, dtype=torch.float64, device=device)
+    mn = torch.empty(B, dtype=torch.float64, device=device)
+    gy = torch.empty_like(y)
+    gc = torch.empty(B, h, w // 2 + 1, dtype=torch.float64, device=device)
+    out = (lp, gy, gc, mn)
+
+    def step():
+        fft.gp_rfft2_lpdf_vjp(y, loc, cov, check=False, out=out)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx = fft.get_context(device)
+    barrier()
+    profile = not args.no_profile
+    if profile:
+        ctx.lib.gpt_profile_begin(ctx.handle)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pass_ms = (ctypes.c_double * 4)()
+    launches = ctypes.c_int64(0)
+    if profile:
+        ctx.lib.gpt_profile_end(ctx.handle, pass_ms, ctypes.byref(launches))
+    barrier()
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity of what was computed in the timed region (not timed): finite values, PD check passed
+    assert bool(torch.isfinite(lp).all()) and float(mn.min()) >= 0.0, "benchmark produced invalid results"
+
+    evals = world * B * args.steps
+    value = evals / elapsed
+    b_alg = 24 * n + 16 * hwf  # bytes per evaluation, BASELINE.md section 3
+    result = {
+        "metric": "gp_rfft2_lpdf+grad evals/sec (fp64, 4096^2)" if size == 4096
+        else f"gp_rfft2_lpdf+grad evals/sec (fp64, {size}^2)",
+        "value": value,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"synthetic {size}x{size} lattice gp_rfft2_lpdf + gradients (d/dy, d/dcov), "
+                        f"batch of {B} lattices per GPU per step, cov/loc shared by the batch",
+            "global_batch": world * B,
+            "parallelism": f"independent lattices sharded over {world} GPU(s), no collective",
+            "path": fft.path_for_shape(h, w),
+        },
+    }
+    if rank == 0:
+        if profile and launches.value > 0:
+            per_eval = [1e-3 * pass_ms[k] / (B * args.steps) for k in range(4)]  # seconds per evaluation
+            pipeline_s = sum(per_eval)
+            pass_bytes = {
+                "row_fwd (pass A)": 16 * n + 8 * n,        # read y, loc; write packed spectrum
+                "col (pass B)": 8 * n + 8 * hwf + 8 * hwf + 8 * n,  # spectrum r/w in place, read c, write dcov
+                "finalize": 0,
+                "row_inv (pass C)": 8 * n + 8 * n,         # read spectrum, write d/dy
+            }
+            kernels = []
+            for (name, nbytes), sec in zip(pass_bytes.items(), per_eval):
+                kernels.append({"name": name, "avg_ms_per_eval": 1e3 * sec, "compulsory_bytes": nbytes,
+                                "GBps": (nbytes / sec / 1e9) if sec > 0 and nbytes else None})
+            achieved = b_alg / pipeline_s / 1e9
+            result["roofline"] = {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s",
+                "frac": achieved * 1e9 / HBM_PEAK,
+                "traffic": None,
+                "kernel": "row_fwd + col + row_inv (three-pass pipeline of one evaluation)",
+                "algorithmic_bytes_per_eval": b_alg,
+                "device_s_per_eval": pipeline_s,
+                "kernels": kernels,
+                "wall_frac": value / world * b_alg / HBM_PEAK,
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(size)
+        print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

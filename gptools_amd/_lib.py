@@ -60,6 +60,8 @@ _PLAIN = {
     "gpt_last_error": ([c_ptr], ctypes.c_char_p),
     "gpt_last_min_eig": ([c_ptr], c_dbl),
     "gpt_version": ([], ctypes.c_char_p),
+    "gpt_profile_begin": ([c_ptr], c_int),
+    "gpt_profile_end": ([c_ptr, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)], c_int),
     "gpt_path_for_shape": ([c_i64, c_i64], c_int),
 }
 

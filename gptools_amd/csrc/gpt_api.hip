@@ -24,6 +24,8 @@ struct gpt_ctx {
     double* pinned = nullptr; // small pinned scratch for scalar read-backs
     std::string err;
     double last_min_eig = NAN;
+    bool profiling = false;              // record events around the passes of the three-pass paths
+    std::vector<hipEvent_t> prof_events; // 5 per chunk launch
 };
 
 namespace {
@@ -160,7 +162,14 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
         if (s.out_c) s.out_c += b0 * hwf;
         if (s.out_lpdf) s.out_lpdf += b0;
         if (s.min_eig) s.min_eig += b0;
-        if (path == 1) HIP_TRY(c, gpt_launch_pow2(op, s, c->ws, c->partials, c->stream));
+        hipEvent_t* ev = nullptr;
+        if (c->profiling) {
+            const size_t at = c->prof_events.size();
+            c->prof_events.resize(at + 5);
+            for (int i = 0; i < 5; ++i) HIP_TRY(c, hipEventCreate(&c->prof_events[at + i]));
+            ev = &c->prof_events[at];
+        }
+        if (path == 1) HIP_TRY(c, gpt_launch_pow2(op, s, c->ws, c->partials, c->stream, ev));
         else HIP_TRY(c, gpt_launch_generic(op, s, c->ws, c->partials, c->stream));
     }
     return GPT_OK;
@@ -249,6 +258,7 @@ int gpt_destroy(gpt_ctx* c) {
     if (!c) return GPT_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     if (c->ws) (void)hipFree(c->ws);
     if (c->partials) (void)hipFree(c->partials);
@@ -270,6 +280,35 @@ int gpt_synchronize(gpt_ctx* c) {
     if (!c) return GPT_ERR_SHAPE;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GPT_OK;
+}
+
+int gpt_profile_begin(gpt_ctx* c) {
+    if (!c) return GPT_ERR_SHAPE;
+    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+    c->prof_events.clear();
+    c->profiling = true;
+    return GPT_OK;
+}
+
+int gpt_profile_end(gpt_ctx* c, double* pass_ms, int64_t* launches) {
+    if (!c) return GPT_ERR_SHAPE;
+    c->profiling = false;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double acc[4] = {0, 0, 0, 0};
+    const size_t n = c->prof_events.size() / 5;
+    for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 4; ++k) {
+            float ms = 0.f;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_events[5 * i + k], c->prof_events[5 * i + k + 1]));
+            acc[k] += ms;
+        }
+    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+    c->prof_events.clear();
+    if (pass_ms)
+        for (int k = 0; k < 4; ++k) pass_ms[k] = acc[k];
+    if (launches) *launches = (int64_t)n;
     return GPT_OK;
 }
 

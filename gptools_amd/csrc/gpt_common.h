@@ -146,63 +146,83 @@ struct EwAcc {
     double mn;  // min of n*c/2 seen
 };
 
+// Per-lattice base pointers (workgroup-uniform: they live in SGPRs); elements are then addressed with
+// 32-bit offsets (H * W < 2^31 as in the reference, fft2.stan:15), one VGPR per address.
+struct EwPtrs {
+    const double* x;
+    const double* cov;
+    const double* aux;
+    const cplx* cin;
+    double* out;
+    double* out_cov;
+    cplx* out_c;
+};
+
+__device__ __forceinline__ EwPtrs make_ptrs(const LatArgs& a, int64_t b) {
+    const int64_t hw = (int64_t)a.H * a.W, hwf = (int64_t)a.H * (a.W / 2 + 1);
+    EwPtrs P;
+    P.x = a.x ? a.x + b * a.x_bs : nullptr;
+    P.cov = a.cov ? a.cov + b * a.cov_bs : nullptr;
+    P.aux = a.aux ? a.aux + b * a.aux_bs : nullptr;
+    P.cin = a.cin ? a.cin + b * a.cin_bs : nullptr;
+    P.out = a.out ? a.out + b * hw : nullptr;
+    P.out_cov = a.out_cov ? a.out_cov + b * hwf : nullptr;
+    P.out_c = a.out_c ? a.out_c + b * hwf : nullptr;
+    return P;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Elementwise stage, INTERIOR entry (i, j), 1 <= j <= wc: a "complex pair" whose Re and Im are both
 // whitened with s^2 = n c / 2 (fft2.stan:13-40, 67-68). F is the spectrum value on entry (ops with a
 // forward transform); the return value replaces it (ops with an inverse transform).
 template <int OP>
-__device__ __forceinline__ cplx ew_interior(const LatArgs& a, const ZLayout& L, int64_t b, int i, int j,
+__device__ __forceinline__ cplx ew_interior(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int i, int j,
                                            cplx F, EwAcc& acc) {
     const double n = (double)a.H * (double)a.W;
-    const int64_t hw = (int64_t)a.H * a.W, hwf = (int64_t)a.H * L.Wf;
+    const unsigned ic = (unsigned)i * (unsigned)L.Wf + (unsigned)j; // offset into H x Wf arrays
+    const unsigned iz = (unsigned)i * (unsigned)a.W;                // row offset into H x W arrays
     cplx ret = F;
     if (OP == OP_RFFT2) {
-        a.out_c[b * hwf + (int64_t)i * L.Wf + j] = F;
+        P.out_c[ic] = F;
         return ret;
     }
     if (OP == OP_INV_RFFT2) {
-        return a.cin[b * a.cin_bs + (int64_t)i * L.Wf + j];
+        return P.cin[ic];
     }
-    const double c = a.cov[b * a.cov_bs + (int64_t)i * L.Wf + j];
+    const double c = P.cov[ic];
     acc.mn = fmin(acc.mn, 0.5 * n * c);
     if (OP == OP_GP_RFFT2) {
         const double inv_s = 1.0 / sqrt(0.5 * n * c);
-        double* o = a.out + b * hw + (int64_t)i * a.W;
-        o[L.re_col(j)] = F.x * inv_s;
-        o[L.im_col(j)] = F.y * inv_s;
+        P.out[iz + L.re_col(j)] = F.x * inv_s;
+        P.out[iz + L.im_col(j)] = F.y * inv_s;
     } else if (OP == OP_GP_INV_RFFT2) {
         const double s = sqrt(0.5 * n * c);
-        const double* z = a.x + b * a.x_bs + (int64_t)i * a.W;
-        ret = make_double2(z[L.re_col(j)] * s, z[L.im_col(j)] * s);
+        ret = make_double2(P.x[iz + L.re_col(j)] * s, P.x[iz + L.im_col(j)] * s);
     } else if (OP == OP_LPDF || OP == OP_LPDF_VJP) {
         const double f2 = fma(F.x, F.x, F.y * F.y);
         const double inv_c = 1.0 / c;
         const double q = f2 * inv_c / n; // |F|^2 / (n c)
         acc.sum -= q + log(c);
         if (OP == OP_LPDF_VJP) {
-            if (a.out_cov) a.out_cov[b * hwf + (int64_t)i * L.Wf + j] = (q - 1.0) * inv_c;
+            if (P.out_cov) P.out_cov[ic] = (q - 1.0) * inv_c;
             ret = cscale(F, inv_c);
         }
     } else if (OP == OP_INV_VJP) {
         // F = R = rfft2(fbar); P = pack(z)
         const double s = sqrt(0.5 * n * c);
-        const double* z = a.x + b * a.x_bs + (int64_t)i * a.W;
-        const double pr = z[L.re_col(j)], pi = z[L.im_col(j)];
-        double* o = a.out + b * hw + (int64_t)i * a.W;
+        const double pr = P.x[iz + L.re_col(j)], pi = P.x[iz + L.im_col(j)];
         const double k2 = 2.0 / n;
-        o[L.re_col(j)] = k2 * s * F.x;
-        o[L.im_col(j)] = k2 * s * F.y;
-        if (a.out_cov) {
+        P.out[iz + L.re_col(j)] = k2 * s * F.x;
+        P.out[iz + L.im_col(j)] = k2 * s * F.y;
+        if (P.out_cov) {
             const double sbar = k2 * fma(pr, F.x, pi * F.y);
-            a.out_cov[b * hwf + (int64_t)i * L.Wf + j] = sbar * s / (2.0 * c);
+            P.out_cov[ic] = sbar * s / (2.0 * c);
         }
     } else if (OP == OP_FWD_VJP) {
         // F = rfft2(y - loc); Q = pack(zbar); returns Dh = Q / (2 s)
         const double s = sqrt(0.5 * n * c);
-        const double* zb = a.aux + b * a.aux_bs + (int64_t)i * a.W;
-        const double qr = zb[L.re_col(j)], qi = zb[L.im_col(j)];
-        if (a.out_cov)
-            a.out_cov[b * hwf + (int64_t)i * L.Wf + j] = -fma(qr, F.x, qi * F.y) / (2.0 * c * s);
+        const double qr = P.aux[iz + L.re_col(j)], qi = P.aux[iz + L.im_col(j)];
+        if (P.out_cov) P.out_cov[ic] = -fma(qr, F.x, qi * F.y) / (2.0 * c * s);
         ret = make_double2(0.5 * qr / s, 0.5 * qi / s);
     }
     return ret;
@@ -215,54 +235,51 @@ __device__ __forceinline__ cplx ew_interior(const LatArgs& a, const ZLayout& L, 
 // scale IS used, row by row, in the inverse direction (fft2.stan:127-128).
 // Returns the replacement value at row k; the caller mirrors it (conj) to row H-k.
 template <int OP>
-__device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, int64_t b, int k, int j, cplx FA,
+__device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k, int j, cplx FA,
                                        EwAcc& acc) {
     const double n = (double)a.H * (double)a.W;
-    const int64_t hw = (int64_t)a.H * a.W, hwf = (int64_t)a.H * L.Wf;
     const bool real_pt = (k == 0) || (2 * k == a.H);
     const int km = real_pt ? k : a.H - k; // mirror row
+    const unsigned ck = (unsigned)k * (unsigned)L.Wf + (unsigned)j, cm_ = (unsigned)km * (unsigned)L.Wf + (unsigned)j;
     cplx ret = FA;
     if (OP == OP_RFFT2) {
-        cplx* o = a.out_c + b * hwf;
         if (real_pt) {
-            o[(int64_t)k * L.Wf + j] = make_double2(FA.x, 0.0);
+            P.out_c[ck] = make_double2(FA.x, 0.0);
         } else {
-            o[(int64_t)k * L.Wf + j] = FA;
-            o[(int64_t)km * L.Wf + j] = cconj(FA);
+            P.out_c[ck] = FA;
+            P.out_c[cm_] = cconj(FA);
         }
         return ret;
     }
     if (OP == OP_INV_RFFT2) {
         // the real part of inv_fft2 keeps the Hermitian part of the column only (util.stan:329)
-        const cplx* zi = a.cin + b * a.cin_bs;
-        const cplx u = zi[(int64_t)k * L.Wf + j];
+        const cplx u = P.cin[ck];
         if (real_pt) return make_double2(u.x, 0.0);
-        const cplx v = zi[(int64_t)km * L.Wf + j];
+        const cplx v = P.cin[cm_];
         return make_double2(0.5 * (u.x + v.x), 0.5 * (u.y - v.y));
     }
-    const double* cb = a.cov + b * a.cov_bs;
-    const double c = cb[(int64_t)k * L.Wf + j];
-    const double cm = real_pt ? c : cb[(int64_t)km * L.Wf + j];
+    const double c = P.cov[ck];
+    const double cm = real_pt ? c : P.cov[cm_];
     acc.mn = fmin(acc.mn, 0.5 * n * fmin(c, cm));
     const int jz = L.edge_col(j);
     // position of Re/Im of row k inside the packed z column (fft1.stan:44-51 along the height);
     // for the 1-D functions H == 1 and only k == 0 exists.
+    const unsigned zr = (unsigned)k * (unsigned)a.W + (unsigned)jz;
+    const unsigned zi = (unsigned)(L.Hf + k - 1) * (unsigned)a.W + (unsigned)jz;
     if (OP == OP_GP_RFFT2) {
-        double* o = a.out + b * hw;
         if (real_pt) {
-            o[(int64_t)k * a.W + jz] = FA.x / sqrt(n * c);
+            P.out[zr] = FA.x / sqrt(n * c);
         } else {
             const double inv_s = 1.0 / sqrt(0.5 * n * c);
-            o[(int64_t)k * a.W + jz] = FA.x * inv_s;
-            o[(int64_t)(L.Hf + k - 1) * a.W + jz] = FA.y * inv_s;
+            P.out[zr] = FA.x * inv_s;
+            P.out[zi] = FA.y * inv_s;
         }
     } else if (OP == OP_GP_INV_RFFT2) {
-        const double* z = a.x + b * a.x_bs;
         if (real_pt) {
-            ret = make_double2(z[(int64_t)k * a.W + jz] * sqrt(n * c), 0.0);
+            ret = make_double2(P.x[zr] * sqrt(n * c), 0.0);
         } else {
             const double se = 0.5 * (sqrt(0.5 * n * c) + sqrt(0.5 * n * cm));
-            ret = make_double2(z[(int64_t)k * a.W + jz] * se, z[(int64_t)(L.Hf + k - 1) * a.W + jz] * se);
+            ret = make_double2(P.x[zr] * se, P.x[zi] * se);
         }
     } else if (OP == OP_LPDF || OP == OP_LPDF_VJP) {
         const double inv_c = 1.0 / c;
@@ -270,55 +287,52 @@ __device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, int6
             const double q = FA.x * FA.x * inv_c / n;
             acc.sum -= 0.5 * (q + log(c));
             if (OP == OP_LPDF_VJP) {
-                if (a.out_cov) a.out_cov[b * hwf + (int64_t)k * L.Wf + j] = 0.5 * (q - 1.0) * inv_c;
+                if (P.out_cov) P.out_cov[ck] = 0.5 * (q - 1.0) * inv_c;
                 ret = make_double2(FA.x * inv_c, 0.0);
             }
         } else {
             const double q = fma(FA.x, FA.x, FA.y * FA.y) * inv_c / n;
             acc.sum -= q + log(c);
             if (OP == OP_LPDF_VJP) {
-                if (a.out_cov) {
-                    a.out_cov[b * hwf + (int64_t)k * L.Wf + j] = (q - 1.0) * inv_c;
-                    a.out_cov[b * hwf + (int64_t)km * L.Wf + j] = 0.0;
+                if (P.out_cov) {
+                    P.out_cov[ck] = (q - 1.0) * inv_c;
+                    P.out_cov[cm_] = 0.0;
                 }
                 ret = cscale(FA, inv_c);
             }
         }
     } else if (OP == OP_INV_VJP) {
-        const double* z = a.x + b * a.x_bs;
-        double* o = a.out + b * hw;
         const double k1 = 1.0 / n;
         if (real_pt) {
             const double s = sqrt(n * c);
-            o[(int64_t)k * a.W + jz] = k1 * s * FA.x;
-            if (a.out_cov) {
-                const double sbar = k1 * z[(int64_t)k * a.W + jz] * FA.x;
-                a.out_cov[b * hwf + (int64_t)k * L.Wf + j] = sbar * s / (2.0 * c);
+            P.out[zr] = k1 * s * FA.x;
+            if (P.out_cov) {
+                const double sbar = k1 * P.x[zr] * FA.x;
+                P.out_cov[ck] = sbar * s / (2.0 * c);
             }
         } else {
             const double s = sqrt(0.5 * n * c), sm = sqrt(0.5 * n * cm);
-            const double pr = z[(int64_t)k * a.W + jz], pi = z[(int64_t)(L.Hf + k - 1) * a.W + jz];
-            o[(int64_t)k * a.W + jz] = k1 * (s + sm) * FA.x;
-            o[(int64_t)(L.Hf + k - 1) * a.W + jz] = k1 * (s + sm) * FA.y;
-            if (a.out_cov) {
+            const double pr = P.x[zr], pi = P.x[zi];
+            P.out[zr] = k1 * (s + sm) * FA.x;
+            P.out[zi] = k1 * (s + sm) * FA.y;
+            if (P.out_cov) {
                 const double sbar = k1 * fma(pr, FA.x, pi * FA.y);
-                a.out_cov[b * hwf + (int64_t)k * L.Wf + j] = sbar * s / (2.0 * c);
-                a.out_cov[b * hwf + (int64_t)km * L.Wf + j] = sbar * sm / (2.0 * cm);
+                P.out_cov[ck] = sbar * s / (2.0 * c);
+                P.out_cov[cm_] = sbar * sm / (2.0 * cm);
             }
         }
     } else if (OP == OP_FWD_VJP) {
-        const double* zb = a.aux + b * a.aux_bs;
         if (real_pt) {
             const double s = sqrt(n * c);
-            const double qr = zb[(int64_t)k * a.W + jz];
-            if (a.out_cov) a.out_cov[b * hwf + (int64_t)k * L.Wf + j] = -(qr * FA.x) / (2.0 * c * s);
+            const double qr = P.aux[zr];
+            if (P.out_cov) P.out_cov[ck] = -(qr * FA.x) / (2.0 * c * s);
             ret = make_double2(qr / s, 0.0);
         } else {
             const double s = sqrt(0.5 * n * c);
-            const double qr = zb[(int64_t)k * a.W + jz], qi = zb[(int64_t)(L.Hf + k - 1) * a.W + jz];
-            if (a.out_cov) {
-                a.out_cov[b * hwf + (int64_t)k * L.Wf + j] = -fma(qr, FA.x, qi * FA.y) / (2.0 * c * s);
-                a.out_cov[b * hwf + (int64_t)km * L.Wf + j] = 0.0;
+            const double qr = P.aux[zr], qi = P.aux[zi];
+            if (P.out_cov) {
+                P.out_cov[ck] = -fma(qr, FA.x, qi * FA.y) / (2.0 * c * s);
+                P.out_cov[cm_] = 0.0;
             }
             ret = make_double2(0.5 * qr / s, 0.5 * qi / s);
         }
@@ -329,14 +343,14 @@ __device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, int6
 // Elementwise stage on the packed column 0 at row k in 0..H/2: Zk = Z[k], Zm = Z[(H-k)%H] on entry
 // (forward ops) and on exit (inverse ops). Splits into the two edge columns, applies ew_edge, recombines.
 template <int OP>
-__device__ __forceinline__ void ew_packed0(const LatArgs& a, const ZLayout& L, int64_t b, int k, cplx& Zk,
+__device__ __forceinline__ void ew_packed0(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k, cplx& Zk,
                                            cplx& Zm, EwAcc& acc) {
     const bool weven = (a.W % 2) == 0;
     // A = (Zk + conj Zm)/2 ; B = (Zk - conj Zm)/(2i)
     cplx A = make_double2(0.5 * (Zk.x + Zm.x), 0.5 * (Zk.y - Zm.y));
     cplx B = make_double2(0.5 * (Zk.y + Zm.y), -0.5 * (Zk.x - Zm.x));
-    A = ew_edge<OP>(a, L, b, k, 0, A, acc);
-    if (weven) B = ew_edge<OP>(a, L, b, k, a.W / 2, B, acc);
+    A = ew_edge<OP>(a, L, P, k, 0, A, acc);
+    if (weven) B = ew_edge<OP>(a, L, P, k, a.W / 2, B, acc);
     else B = make_double2(0.0, 0.0);
     if (op_has_inv(OP)) {
         // Z[k] = A + iB ; Z[H-k] = conj(A) + i conj(B)

@@ -13,7 +13,9 @@ hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st);
 bool gpt_pow2_supported(int H, int W);
 size_t gpt_pow2_workspace_bytes(int H, int W);
 int gpt_pow2_col_blocks(int H, int W);
-hipError_t gpt_launch_pow2(int op, const LatArgs& a, cplx* ws, double* partials, hipStream_t st);
+// `ev` (may be null): 5 events recorded before pass A, after pass A, after pass B, after the finalize
+// kernel and after pass C (profiling mode of the context).
+hipError_t gpt_launch_pow2(int op, const LatArgs& a, cplx* ws, double* partials, hipStream_t st, hipEvent_t* ev);
 
 // --- generic large path (gpt_generic.hip): any H, W whose lines fit LDS
 bool gpt_generic_supported(int H, int W);

@@ -1,6 +1,69 @@
-#include "gpt_common.h"
-#include "gpt_host.h"
-bool gpt_pow2_supported(int, int) { return false; }
-size_t gpt_pow2_workspace_bytes(int, int) { return 0; }
-int gpt_pow2_col_blocks(int, int) { return 1; }
-hipError_t gpt_launch_pow2(int, const LatArgs&, cplx*, double*, hipStream_t) { return hipErrorNotSupported; }
+// Dispatcher of the power-of-two three-pass path (kernels in gpt_pow2_impl.h / gpt_pow2_n.hip).
+#include "gpt_pow2_impl.h"
+
+namespace {
+bool is_pow2_in_range(int n) { return n >= 256 && n <= 8192 && (n & (n - 1)) == 0; }
+
+template <typename F> hipError_t by_size(int n, F f) {
+    switch (n) {
+    case 256: return f(pow2::Launch<256>());
+    case 512: return f(pow2::Launch<512>());
+    case 1024: return f(pow2::Launch<1024>());
+    case 2048: return f(pow2::Launch<2048>());
+    case 4096: return f(pow2::Launch<4096>());
+    case 8192: return f(pow2::Launch<8192>());
+    default: return hipErrorInvalidValue;
+    }
+}
+} // namespace
+
+bool gpt_pow2_supported(int H, int W) { return is_pow2_in_range(H) && is_pow2_in_range(W); }
+
+size_t gpt_pow2_workspace_bytes(int H, int W) { return (size_t)H * (size_t)(W / 2 + GPT_WS_PAD) * sizeof(cplx); }
+
+int gpt_pow2_col_blocks(int H, int W) {
+    int nb = 1;
+    (void)by_size(H, [&](auto l) {
+        nb = decltype(l)::col_blocks(W);
+        return hipSuccess;
+    });
+    return nb;
+}
+
+hipError_t gpt_launch_pow2(int op, const LatArgs& a, cplx* ws, double* partials, hipStream_t st, hipEvent_t* ev) {
+    if (!gpt_pow2_supported(a.H, a.W)) return hipErrorInvalidValue;
+    const int wstride = a.W / 2 + GPT_WS_PAD;
+    const double n = (double)a.H * (double)a.W;
+    hipError_t e = hipSuccess;
+    auto mark = [&](int i) {
+        if (ev) (void)hipEventRecord(ev[i], st);
+    };
+    mark(0);
+    if (op_has_fwd(op)) {
+        const int in_mode = op == OP_RFFT2 ? 0 : (op == OP_INV_VJP ? 2 : 1);
+        e = by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, in_mode, ws, wstride, st); });
+        if (e != hipSuccess) return e;
+    }
+    mark(1);
+    e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, ws, wstride, partials, st); });
+    if (e != hipSuccess) return e;
+    mark(2);
+    if (op != OP_RFFT2 && op != OP_INV_RFFT2) {
+        const int nblk = gpt_pow2_col_blocks(a.H, a.W);
+        const bool lp = (op == OP_LPDF || op == OP_LPDF_VJP);
+        e = gpt_launch_finalize(partials, nblk, a.batch, 1, -0.5 * n * 1.8378770664093454836,
+                                lp ? a.out_lpdf : nullptr, a.min_eig, st);
+        if (e != hipSuccess) return e;
+    }
+    mark(3);
+    if (op_has_inv(op)) {
+        double alpha = 1.0;
+        int add_loc = 0;
+        if (op == OP_INV_RFFT2) alpha = 1.0 / n;
+        else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
+        else if (op == OP_LPDF_VJP) alpha = -1.0 / n;
+        e = by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, st); });
+    }
+    mark(4);
+    return e;
+}

@@ -1,0 +1,403 @@
+// Power-of-two three-pass path (the 4096 x 4096 headline shape): templates, instantiated once per line
+// length N in gpt_pow2_n.hip.
+//
+//   pass A  row_fwd   one workgroup per ROW PAIR: (y - loc) of rows 2r, 2r+1 -> one complex line of length
+//                     W (two-for-one real transform), register-resident radix-16 Stockham FFT, split, write
+//                     the packed half spectrum S[H][W/2] (DC + i*Nyquist in column 0).
+//   pass B  col       one workgroup per TC adjacent packed columns: column FFT (length H), the op's
+//                     elementwise stage (log-density terms, F/c, d/dcov, ...) on registers, inverse column
+//                     FFT, write back IN PLACE. Wavefront shuffle + LDS reduction -> per-workgroup partials.
+//   pass C  row_inv   one workgroup per row pair: merge the two half spectra into one complex line,
+//                     inverse FFT, write the two real rows (scaled, +loc / negated as the op needs).
+//
+// Line FFT: each thread keeps E = 16 complex fp64 elements in registers (v[m] <-> element t + T*m,
+// T = N/16 threads per line). Every Stockham stage is a radix-16 (last stage 2/4/8/16) butterfly on
+// registers followed by an exchange through LDS; LDS is addressed through an XOR swizzle so that both the
+// strided writes and the contiguous reads of an exchange are (nearly) bank-conflict free without padding:
+// a 4096-point line needs exactly 64 KB.
+#pragma once
+#include "gpt_common.h"
+#include "gpt_host.h"
+
+namespace pow2 {
+
+constexpr int E = 16;
+
+__device__ __forceinline__ int phys(int o) { return o ^ ((o >> 4) & 15); }
+
+template <bool INV> __device__ __forceinline__ cplx tw_dir(cplx w) {
+    if (INV) w.y = -w.y;
+    return w;
+}
+
+// multiply by -i (forward) / +i (inverse)
+template <bool INV> __device__ __forceinline__ cplx mul_mi(cplx a) {
+    return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+}
+
+template <bool INV> __device__ __forceinline__ void bfly2(cplx& a, cplx& b) {
+    const cplx t = csub(a, b);
+    a = cadd(a, b);
+    b = t;
+}
+
+// 4-point DFT, natural order in and out: X[p] = sum_q x[q] w4^{qp}
+template <bool INV> __device__ __forceinline__ void bfly4(cplx& x0, cplx& x1, cplx& x2, cplx& x3) {
+    const cplx a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d = mul_mi<INV>(csub(x1, x3));
+    x0 = cadd(a, c);
+    x1 = cadd(b, d);
+    x2 = csub(a, c);
+    x3 = csub(b, d);
+}
+
+template <int R, bool INV> struct Bfly;
+
+template <bool INV> struct Bfly<2, INV> {
+    static __device__ __forceinline__ void run(cplx* x) { bfly2<INV>(x[0], x[1]); }
+};
+template <bool INV> struct Bfly<4, INV> {
+    static __device__ __forceinline__ void run(cplx* x) { bfly4<INV>(x[0], x[1], x[2], x[3]); }
+};
+template <bool INV> struct Bfly<8, INV> {
+    // 8 = 2 (q1) x 4 (q2): X[p1 + 2 p2] = sum_q2 w8^{q2 p1} (sum_q1 x[4 q1 + q2] w2^{q1 p1}) w4^{q2 p2}
+    static __device__ __forceinline__ void run(cplx* x) {
+        constexpr double h = 0.70710678118654752440;
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) bfly2<INV>(x[q2], x[4 + q2]);
+        // rows p1 = 0: x[0..3]; p1 = 1: x[4..7] times w8^{q2}
+        x[5] = INV ? make_double2(h * (x[5].x - x[5].y), h * (x[5].x + x[5].y))
+                   : make_double2(h * (x[5].x + x[5].y), h * (x[5].y - x[5].x));
+        x[6] = mul_mi<INV>(x[6]);
+        x[7] = INV ? make_double2(-h * (x[7].x + x[7].y), h * (x[7].x - x[7].y))
+                   : make_double2(h * (x[7].y - x[7].x), -h * (x[7].x + x[7].y));
+        bfly4<INV>(x[0], x[1], x[2], x[3]); // p1 = 0 -> outputs X[0 + 2 p2]
+        bfly4<INV>(x[4], x[5], x[6], x[7]); // p1 = 1 -> outputs X[1 + 2 p2]
+        // reorder: currently x[p2] = X[2 p2], x[4 + p2] = X[1 + 2 p2]
+        const cplx t1 = x[1], t2 = x[2], t3 = x[3], t4 = x[4], t5 = x[5], t6 = x[6];
+        x[1] = t4; x[2] = t1; x[3] = t5; x[4] = t2; x[5] = t6; x[6] = t3;
+    }
+};
+template <bool INV> struct Bfly<16, INV> {
+    // 16 = 4 (q1) x 4 (q2): X[p1 + 4 p2] = sum_q2 w16^{q2 p1} (sum_q1 x[4 q1 + q2] w4^{q1 p1}) w4^{q2 p2}
+    static __device__ __forceinline__ void run(cplx* x) {
+        constexpr double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173; // cos, sin(pi/8)
+        constexpr double h = 0.70710678118654752440;
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) bfly4<INV>(x[q2], x[4 + q2], x[8 + q2], x[12 + q2]);
+        // now x[4 p1 + q2] = y[p1][q2]; twiddle by w16^{q2 p1} = exp(-+ 2 pi i q2 p1 / 16)
+        auto tw = [](cplx a, double c, double s) -> cplx { // a * (c - i s) forward, a * (c + i s) inverse
+            return INV ? make_double2(a.x * c - a.y * s, a.y * c + a.x * s)
+                       : make_double2(a.x * c + a.y * s, a.y * c - a.x * s);
+        };
+        // p1 = 1: exponents 1, 2, 3
+        x[5] = tw(x[5], c1, s1);
+        x[6] = tw(x[6], h, h);
+        x[7] = tw(x[7], s1, c1);
+        // p1 = 2: exponents 2, 4, 6
+        x[9] = tw(x[9], h, h);
+        x[10] = mul_mi<INV>(x[10]);
+        x[11] = tw(x[11], -h, h);
+        // p1 = 3: exponents 3, 6, 9
+        x[13] = tw(x[13], s1, c1);
+        x[14] = tw(x[14], -h, h);
+        x[15] = tw(x[15], -c1, -s1);
+#pragma unroll
+        for (int p1 = 0; p1 < 4; ++p1) bfly4<INV>(x[4 * p1], x[4 * p1 + 1], x[4 * p1 + 2], x[4 * p1 + 3]);
+        // x[4 p1 + p2] = X[p1 + 4 p2] -> transpose the 4 x 4 register tile
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = a + 1; b < 4; ++b) {
+                const cplx t = x[4 * a + b];
+                x[4 * a + b] = x[4 * b + a];
+                x[4 * b + a] = t;
+            }
+    }
+};
+
+// One Stockham stage on registers: U = E/R butterflies of radix R per thread.
+template <int N, int R, int NS, bool INV>
+__device__ __forceinline__ void stage_bfly(cplx (&v)[E], int t, const cplx* __restrict__ tw) {
+    constexpr int T = N / E, U = E / R;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        cplx x[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) x[q] = v[u + q * U];
+        if (NS > 1) {
+            constexpr int tstep = N / (NS * R);
+            const int k = (t + T * u) & (NS - 1);
+#pragma unroll
+            for (int q = 1; q < R; ++q) {
+                const cplx w = tw_dir<INV>(tw[(q * k * tstep) & (N - 1)]);
+                x[q] = cmul(x[q], w);
+            }
+        }
+        Bfly<R, INV>::run(x);
+#pragma unroll
+        for (int p = 0; p < R; ++p) v[u + p * U] = x[p];
+    }
+}
+
+// Exchange after a (non-final) stage: scatter the butterfly outputs to their Stockham positions, gather
+// back the elements t + T*m the next stage needs.
+template <int N, int R, int NS>
+__device__ __forceinline__ void exchange(cplx (&v)[E], int t, cplx* lds) {
+    constexpr int T = N / E, U = E / R;
+    __syncthreads(); // everyone is done reading the previous contents of this LDS region
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = t + T * u;
+        const int o0 = (j / NS) * NS * R + (j & (NS - 1));
+#pragma unroll
+        for (int p = 0; p < R; ++p) lds[phys(o0 + p * NS)] = v[u + p * U];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E; ++m) v[m] = lds[phys(t + T * m)];
+}
+
+template <int N, int NS, bool INV>
+__device__ __forceinline__ void fft_rec(cplx (&v)[E], int t, cplx* lds, const cplx* __restrict__ tw) {
+    constexpr int REM = N / NS;
+    constexpr int R = REM >= 16 ? 16 : REM;
+    stage_bfly<N, R, NS, INV>(v, t, tw);
+    if constexpr (NS * R < N) {
+        exchange<N, R, NS>(v, t, lds);
+        fft_rec<N, NS * R, INV>(v, t, lds, tw);
+    }
+}
+
+// In: v[m] = x[t + T m]. Out: v[m] = X[t + T m] (natural order). `lds` is this line's N-element region.
+template <int N, bool INV>
+__device__ __forceinline__ void fft_regs(cplx (&v)[E], int t, cplx* lds, const cplx* __restrict__ tw) {
+    fft_rec<N, 1, INV>(v, t, lds, tw);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Geometry of the workgroups.
+template <int N> struct Geo {
+    static constexpr int T = N / E;                      // threads per line
+    static constexpr int ROW_THREADS = T < 256 ? 256 : T; // row kernels: >= 256 threads
+    static constexpr int ROW_LINES = ROW_THREADS / T;     // row pairs per workgroup
+    static constexpr int COL_THREADS = T < 512 ? 512 : T; // column kernel
+    static constexpr int TC = COL_THREADS / T;            // adjacent packed columns per workgroup
+};
+
+// pass A --------------------------------------------------------------------------------------------
+// in_mode: 0 = x, 1 = x - loc, 2 = aux
+template <int W>
+__global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a, int in_mode, cplx* __restrict__ ws,
+                                                                      int wstride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = Geo<W>::T, LINES = Geo<W>::ROW_LINES;
+    const int line = threadIdx.x / T, t = threadIdx.x - line * T;
+    cplx* lds = reinterpret_cast<cplx*>(smem) + (size_t)line * W;
+    const int64_t b = blockIdx.y;
+    const int H = a.H;
+    const int npairs = H / 2;
+    const int r = blockIdx.x * LINES + line; // row pair
+    const bool active = r < npairs;
+    const int rr = active ? r : 0;
+    const double* src = in_mode == 2 ? a.aux + b * a.aux_bs : a.x + b * a.x_bs;
+    const double* r0 = src + (int64_t)(2 * rr) * W;
+    const double* r1 = r0 + W;
+    cplx v[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) v[m] = make_double2(r0[t + T * m], r1[t + T * m]);
+    if (in_mode == 1 && a.loc) {
+        const double* l0 = a.loc + b * a.loc_bs + (int64_t)(2 * rr) * W;
+        const double* l1 = l0 + W;
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            v[m].x -= l0[t + T * m];
+            v[m].y -= l1[t + T * m];
+        }
+    }
+    fft_regs<W, false>(v, t, lds, a.pw.tw);
+    // split the two rows: need Z[j] (own registers) and Z[W - j] (through LDS)
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m];
+    __syncthreads();
+    if (!active) return;
+    cplx* s0 = ws + ((int64_t)b * H + 2 * rr) * wstride;
+    cplx* s1 = s0 + wstride;
+#pragma unroll
+    for (int m = 0; m < E / 2; ++m) {
+        const int j = t + T * m;
+        const cplx z = v[m];
+        if (j == 0) {
+            const cplx zn = v[E / 2]; // Z[W/2] lives in the same thread (t == 0, m == E/2)
+            s0[0] = make_double2(z.x, zn.x);
+            s1[0] = make_double2(z.y, zn.y);
+        } else {
+            const cplx zc = lds[phys(W - j)];
+            s0[j] = make_double2(0.5 * (z.x + zc.x), 0.5 * (z.y - zc.y));
+            s1[j] = make_double2(0.5 * (z.y + zc.y), -0.5 * (z.x - zc.x));
+        }
+    }
+}
+
+// pass C --------------------------------------------------------------------------------------------
+// out = alpha * value (+ loc when add_loc)
+template <int W>
+__global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a, double alpha, int add_loc,
+                                                                      const cplx* __restrict__ ws, int wstride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = Geo<W>::T, LINES = Geo<W>::ROW_LINES;
+    const int line = threadIdx.x / T, t = threadIdx.x - line * T;
+    cplx* lds = reinterpret_cast<cplx*>(smem) + (size_t)line * W;
+    const int64_t b = blockIdx.y;
+    const int H = a.H;
+    const int r = blockIdx.x * LINES + line;
+    const bool active = r < H / 2;
+    const int rr = active ? r : 0;
+    const cplx* s0 = ws + ((int64_t)b * H + 2 * rr) * wstride;
+    const cplx* s1 = s0 + wstride;
+    cplx v[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const int j = t + T * m;
+        if (m < E / 2) {
+            const cplx A = s0[j], B = s1[j];
+            if (j == 0) v[m] = make_double2(A.x, B.x); // DC terms are real
+            else v[m] = make_double2(A.x - B.y, A.y + B.x);
+        } else {
+            const int q = W - j; // 1 .. W/2
+            if (q == W / 2) {
+                const cplx A = s0[0], B = s1[0];
+                v[m] = make_double2(A.y, B.y); // Nyquist terms ride in the imaginary slot of column 0
+            } else {
+                const cplx A = s0[q], B = s1[q];
+                v[m] = make_double2(A.x + B.y, -A.y + B.x); // conj(A) + i conj(B)
+            }
+        }
+    }
+    fft_regs<W, true>(v, t, lds, a.pw.tw);
+    if (!active) return;
+    double* o0 = a.out + b * (int64_t)H * W + (int64_t)(2 * rr) * W;
+    double* o1 = o0 + W;
+    if (add_loc && a.loc) {
+        const double* l0 = a.loc + b * a.loc_bs + (int64_t)(2 * rr) * W;
+        const double* l1 = l0 + W;
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            o0[t + T * m] = fma(alpha, v[m].x, l0[t + T * m]);
+            o1[t + T * m] = fma(alpha, v[m].y, l1[t + T * m]);
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            o0[t + T * m] = alpha * v[m].x;
+            o1[t + T * m] = alpha * v[m].y;
+        }
+    }
+}
+
+// pass B --------------------------------------------------------------------------------------------
+template <int H, int OP>
+__global__ void __launch_bounds__(Geo<H>::COL_THREADS) col_kernel(LatArgs a, cplx* __restrict__ ws, int wstride,
+                                                                  double* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = Geo<H>::T, TC = Geo<H>::TC;
+    const int c = threadIdx.x % TC, t = threadIdx.x / TC;
+    cplx* lds = reinterpret_cast<cplx*>(smem) + (size_t)c * H;
+    double* red = reinterpret_cast<double*>(smem); // reused after the FFTs are done with LDS
+    const int64_t b = blockIdx.y;
+    const int j0 = blockIdx.x * TC;
+    const int jp = j0 + c; // packed column
+    const ZLayout L = make_layout(a);
+    const EwPtrs P = make_ptrs(a, b);
+    cplx* wsb = ws + (int64_t)b * H * wstride; // uniform base; 32-bit element offsets below
+    cplx v[E];
+    if (op_has_fwd(OP)) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m] = wsb[(unsigned)(t + T * m) * (unsigned)wstride + (unsigned)jp];
+        fft_regs<H, false>(v, t, lds, a.ph.tw);
+    } else {
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m] = make_double2(0.0, 0.0);
+    }
+    EwAcc acc;
+    acc.sum = 0.0;
+    acc.mn = INFINITY;
+    if (j0 == 0) { // workgroup-uniform: this workgroup owns the packed column 0
+        __syncthreads();
+        if (c == 0) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m];
+        }
+        __syncthreads();
+        if (c == 0) {
+#pragma unroll
+            for (int m = 0; m <= E / 2; ++m) {
+                const int k = t + T * m;
+                if (k <= H / 2) {
+                    const bool self = (k == 0) || (k == H / 2);
+                    cplx Zk = v[m];
+                    cplx Zm = self ? Zk : lds[phys(H - k)];
+                    ew_packed0<OP>(a, L, P, k, Zk, Zm, acc);
+                    if (op_has_inv(OP)) {
+                        v[m] = Zk;
+                        if (!self) lds[phys(H - k)] = Zm;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (c == 0 && op_has_inv(OP)) {
+#pragma unroll
+            for (int m = E / 2; m < E; ++m) {
+                const int k = t + T * m;
+                if (k > H / 2) v[m] = lds[phys(k)];
+            }
+        }
+        if (c != 0) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                v[m] = ew_interior<OP>(a, L, P, t + T * m, jp, v[m], acc);
+                if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            v[m] = ew_interior<OP>(a, L, P, t + T * m, jp, v[m], acc);
+            if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (op_has_inv(OP)) {
+        // Launder the table pointer: otherwise the compiler keeps all 30 twiddles of the forward transform
+        // alive across the elementwise stage to reuse them here (120 VGPRs -> spills).
+        // The same goes for the thread index all LDS addresses derive from.
+        const cplx* tw_inv = a.ph.tw;
+        int t_inv = t;
+        asm volatile("" : "+s"(tw_inv));
+        asm volatile("" : "+v"(t_inv));
+        fft_regs<H, true>(v, t_inv, lds, tw_inv);
+#pragma unroll
+        for (int m = 0; m < E; ++m) wsb[(unsigned)(t_inv + T * m) * (unsigned)wstride + (unsigned)jp] = v[m];
+    }
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
+        double s = acc.sum, mn = acc.mn;
+        block_sum_min(s, mn, red);
+        if (threadIdx.x == 0) {
+            double* p = partials + ((int64_t)b * gridDim.x + blockIdx.x) * GPT_PART;
+            p[0] = s;
+            p[1] = p[2] = p[3] = p[4] = 0.0;
+            p[5] = mn;
+        }
+    }
+}
+
+template <int N> struct Launch {
+    static hipError_t row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, hipStream_t st);
+    static hipError_t row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
+                              hipStream_t st);
+    static hipError_t col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, hipStream_t st);
+    static int col_blocks(int W) { return (W / 2) / Geo<N>::TC; }
+};
+
+} // namespace pow2

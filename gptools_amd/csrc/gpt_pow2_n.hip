@@ -1,0 +1,69 @@
+// One translation unit per line length: compiled with -DGPT_N=<256|512|1024|2048|4096|8192>.
+#include "gpt_pow2_impl.h"
+
+#ifndef GPT_N
+#error "compile with -DGPT_N=<power of two>"
+#endif
+
+namespace pow2 {
+
+namespace {
+template <typename K> hipError_t raise_lds(K kernel, size_t lds) {
+    if (lds <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds);
+}
+} // namespace
+
+template <>
+hipError_t Launch<GPT_N>::row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, hipStream_t st) {
+    constexpr int W = GPT_N;
+    const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(cplx);
+    hipError_t e = raise_lds(row_fwd_kernel<W>, lds);
+    if (e != hipSuccess) return e;
+    const int npairs = a.H / 2;
+    dim3 grid((npairs + Geo<W>::ROW_LINES - 1) / Geo<W>::ROW_LINES, (unsigned)a.batch);
+    hipLaunchKernelGGL(row_fwd_kernel<W>, grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, in_mode, ws, wstride);
+    return hipGetLastError();
+}
+
+template <>
+hipError_t Launch<GPT_N>::row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
+                                  hipStream_t st) {
+    constexpr int W = GPT_N;
+    const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(cplx);
+    hipError_t e = raise_lds(row_inv_kernel<W>, lds);
+    if (e != hipSuccess) return e;
+    const int npairs = a.H / 2;
+    dim3 grid((npairs + Geo<W>::ROW_LINES - 1) / Geo<W>::ROW_LINES, (unsigned)a.batch);
+    hipLaunchKernelGGL(row_inv_kernel<W>, grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, alpha, add_loc, ws, wstride);
+    return hipGetLastError();
+}
+
+template <int OP>
+static hipError_t col_t(const LatArgs& a, cplx* ws, int wstride, double* partials, hipStream_t st) {
+    constexpr int H = GPT_N;
+    const size_t lds = (size_t)Geo<H>::TC * H * sizeof(cplx);
+    hipError_t e = raise_lds(col_kernel<H, OP>, lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((a.W / 2) / Geo<H>::TC, (unsigned)a.batch);
+    hipLaunchKernelGGL((col_kernel<H, OP>), grid, dim3(Geo<H>::COL_THREADS), lds, st, a, ws, wstride, partials);
+    return hipGetLastError();
+}
+
+template <>
+hipError_t Launch<GPT_N>::col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, hipStream_t st) {
+    switch (op) {
+    case OP_RFFT2: return col_t<OP_RFFT2>(a, ws, wstride, partials, st);
+    case OP_INV_RFFT2: return col_t<OP_INV_RFFT2>(a, ws, wstride, partials, st);
+    case OP_GP_RFFT2: return col_t<OP_GP_RFFT2>(a, ws, wstride, partials, st);
+    case OP_GP_INV_RFFT2: return col_t<OP_GP_INV_RFFT2>(a, ws, wstride, partials, st);
+    case OP_LPDF: return col_t<OP_LPDF>(a, ws, wstride, partials, st);
+    case OP_LPDF_VJP: return col_t<OP_LPDF_VJP>(a, ws, wstride, partials, st);
+    case OP_INV_VJP: return col_t<OP_INV_VJP>(a, ws, wstride, partials, st);
+    case OP_FWD_VJP: return col_t<OP_FWD_VJP>(a, ws, wstride, partials, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace pow2

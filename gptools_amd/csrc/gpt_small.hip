@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
     const int64_t b = blockIdx.x;
     const int H = a.H, W = a.W;
     const ZLayout L = make_layout(a);
+    const EwPtrs P = make_ptrs(a, b);
     const int NC = 1 + L.wc;
     const int Hp = (H + 1) / 2;
     const bool weven = (W % 2) == 0;
@@ -131,13 +132,13 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
     for (int w = threadIdx.x; w < H * L.wc; w += blockDim.x) {
         const int i = w / L.wc, j = 1 + (w - i * L.wc);
         const cplx F = cur[i * sS + j];
-        const cplx G = ew_interior<OP>(a, L, b, i, j, F, acc);
+        const cplx G = ew_interior<OP>(a, L, P, i, j, F, acc);
         if (op_has_inv(OP)) cur[i * sS + j] = G;
     }
     for (int k = threadIdx.x; k <= H / 2; k += blockDim.x) {
         const int km = (H - k) % H;
         cplx Zk = cur[k * sS], Zm = cur[km * sS];
-        ew_packed0<OP>(a, L, b, k, Zk, Zm, acc);
+        ew_packed0<OP>(a, L, P, k, Zk, Zm, acc);
         if (op_has_inv(OP)) {
             cur[k * sS] = Zk;
             if (km != k) cur[km * sS] = Zm;

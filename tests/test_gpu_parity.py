@@ -249,3 +249,74 @@ def test_host_entry_points_col_major(fft):
         assert rc == _lib.GPT_ERR_NOT_PD
         assert "not positive-definite" in ctx.error()
         assert lib.gpt_last_min_eig(ctx.handle) < 0
+
+
+# ---- three-pass paths (lattices too large for one workgroup's LDS) ----------------------------------
+BIG_SHAPES = [(256, 256), (256, 512), (512, 256), (1024, 256)]
+
+
+@pytest.mark.parametrize("shape", BIG_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+def test_three_pass_path_vs_oracle(fft, shape):
+    """Every lattice function on the three-pass kernels, batch of 2, against the oracle."""
+    h, w = shape
+    assert fft.path_for_shape(h, w) in (1, 2)
+    rng = np.random.default_rng(100 * h + w)
+    y = rng.normal(size=(2, h, w))
+    loc = rng.normal(size=(h, w))
+    cov = o.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.3, [h / 40.0, w / 30.0], [float(h), float(w)]) + 1e-3
+    cov = cov * np.exp(0.1 * rng.normal(size=cov.shape))  # break the row symmetry
+    z = rng.normal(size=(2, h, w))
+    bar = rng.normal(size=(2, h, w))
+    close(fft.rfft2(y), o.rfft2(y))
+    close(fft.inv_rfft2(o.rfft2(y), w), y)
+    close(fft.gp_rfft2(y, loc, cov), o.gp_rfft2(y, loc, cov))
+    close(fft.gp_inv_rfft2(z, loc, cov), o.gp_inv_rfft2(z, loc, cov))
+    lp, gy, gc = fft.gp_rfft2_lpdf_vjp(y, loc, cov)
+    lp_o, gy_o, gc_o = o.gp_rfft2_lpdf_vjp(y, loc, cov)
+    close(lp, lp_o)
+    close(gy, gy_o)
+    close(gc, gc_o)
+    close(fft.gp_rfft2_lpdf(y, loc, cov), lp_o)
+    zb, cb = fft.gp_inv_rfft2_vjp(z, cov, bar)
+    zb_o, _, cb_o = o.gp_inv_rfft2_vjp(z, loc, cov, bar)
+    close(zb, zb_o)
+    close(cb, cb_o)
+    yb, cb2 = fft.gp_rfft2_vjp(y, loc, cov, bar)
+    yb_o, _, cb2_o = o.gp_rfft2_vjp(y, loc, cov, bar)
+    close(yb, yb_o)
+    close(cb2, cb2_o)
+    bad = cov.copy()
+    bad[h - 1, 0] = -1.0
+    with pytest.raises(ValueError, match="not positive-definite"):
+        fft.gp_rfft2_lpdf(y, loc, bad)
+
+
+def test_headline_shape_4096(fft):
+    """BASELINE config 4 (4096 x 4096): value and gradients against the oracle on one lattice, plus
+    size-independent properties: transform round trip and linearity of the gradient in (y - loc)."""
+    import torch
+
+    h = w = 4096
+    rng = np.random.default_rng(4096)
+    cov = o.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.3, [8.0, 12.0], [float(h), float(w)]) + 1e-3
+    loc = rng.normal(size=(h, w))
+    z = rng.normal(size=(h, w))
+    dev = torch.device("cuda:0")
+    cov_d, loc_d, z_d = (torch.as_tensor(x, device=dev) for x in (cov, loc, z))
+    y_d = fft.gp_inv_rfft2(z_d, loc_d, cov_d)
+    # round trip: gp_rfft2(gp_inv_rfft2(z)) == z (test_fft.py:114-126 at full size)
+    close(fft.gp_rfft2(y_d, loc_d, cov_d), z, rtol=1e-9)
+    lp, gy, gc = fft.gp_rfft2_lpdf_vjp(y_d, loc_d, cov_d)
+    y = y_d.cpu().numpy()
+    close(y, o.gp_inv_rfft2(z, loc, cov))
+    lp_o, gy_o, gc_o = o.gp_rfft2_lpdf_vjp(y, loc, cov)
+    close(lp, lp_o)
+    close(gy, gy_o)
+    close(gc, gc_o)
+    # lpdf = -1/2 |z|^2 - n/2 log(2 pi) + log|J| with z the whitened coefficients
+    ladj = fft.gp_rfft2_log_abs_det_jac(cov_d, w)
+    want = -0.5 * float((z_d * z_d).sum()) - 0.5 * h * w * np.log(2 * np.pi) + float(ladj)
+    close(lp, want, rtol=1e-9)
+    # the gradient w.r.t. y is linear in (y - loc): grad(loc + 2 (y - loc)) == 2 grad(y)
+    _, gy2, _ = fft.gp_rfft2_lpdf_vjp(loc_d + 2.0 * (y_d - loc_d), loc_d, cov_d, need_cov_grad=False)
+    close(gy2, 2.0 * gy.cpu().numpy(), rtol=1e-9)
