@@ -22,6 +22,7 @@
 namespace pow2 {
 
 constexpr int E = 16;
+constexpr int COL_SKEW = 8;
 
 __device__ __forceinline__ int phys(int o) { return o ^ ((o >> 4) & 15); }
 
@@ -302,10 +303,21 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS) col_kernel(LatArgs a, cpl
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int T = Geo<H>::T, TC = Geo<H>::TC;
     const int c = threadIdx.x % TC, t = threadIdx.x / TC;
-    cplx* lds = reinterpret_cast<cplx*>(smem) + (size_t)c * H;
+    // adjacent columns' regions are skewed by 8 elements (128 B): the lanes of one LDS lane group alternate
+    // between columns, and an unskewed region start would put them on the same banks (2-way conflict)
+    cplx* lds = reinterpret_cast<cplx*>(smem) + (size_t)c * (H + COL_SKEW);
     double* red = reinterpret_cast<double*>(smem); // reused after the FFTs are done with LDS
     const int64_t b = blockIdx.y;
-    const int j0 = blockIdx.x * TC;
+    // XCD-aware mapping. Workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 labels the XCD),
+    // and 16 / TC neighbouring column groups read pieces of the SAME 128-byte lines of the spectrum, of
+    // cov and of d/dcov. Give each XCD a contiguous range of column groups, in dispatch order, so that the
+    // sharers meet in one L2 instead of each XCD fetching every line again (speed only, never correctness).
+    int grp = blockIdx.x;
+    {
+        const int ng = gridDim.x;
+        if ((ng & 7) == 0) grp = (blockIdx.x & 7) * (ng >> 3) + (blockIdx.x >> 3);
+    }
+    const int j0 = grp * TC;
     const int jp = j0 + c; // packed column
     const ZLayout L = make_layout(a);
     const EwPtrs P = make_ptrs(a, b);
@@ -384,7 +396,7 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS) col_kernel(LatArgs a, cpl
         double s = acc.sum, mn = acc.mn;
         block_sum_min(s, mn, red);
         if (threadIdx.x == 0) {
-            double* p = partials + ((int64_t)b * gridDim.x + blockIdx.x) * GPT_PART;
+            double* p = partials + ((int64_t)b * gridDim.x + grp) * GPT_PART;
             p[0] = s;
             p[1] = p[2] = p[3] = p[4] = 0.0;
             p[5] = mn;

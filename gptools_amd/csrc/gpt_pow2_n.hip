@@ -43,7 +43,7 @@ hipError_t Launch<GPT_N>::row_inv(const LatArgs& a, double alpha, int add_loc, c
 template <int OP>
 static hipError_t col_t(const LatArgs& a, cplx* ws, int wstride, double* partials, hipStream_t st) {
     constexpr int H = GPT_N;
-    const size_t lds = (size_t)Geo<H>::TC * H * sizeof(cplx);
+    const size_t lds = (size_t)Geo<H>::TC * (H + COL_SKEW) * sizeof(cplx);
     hipError_t e = raise_lds(col_kernel<H, OP>, lds);
     if (e != hipSuccess) return e;
     dim3 grid((a.W / 2) / Geo<H>::TC, (unsigned)a.batch);
