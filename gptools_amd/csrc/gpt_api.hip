@@ -19,6 +19,8 @@ struct gpt_ctx {
     size_t ws_bytes = 0;
     double* partials = nullptr;
     size_t partials_bytes = 0;
+    double* sink = nullptr; // write-only dump for gradients the caller did not ask for
+    size_t sink_bytes = 0;
     char* arena = nullptr; // device staging arena of the host-pointer entry points
     size_t arena_bytes = 0;
     double* pinned = nullptr; // small pinned scratch for scalar read-backs
@@ -263,6 +265,7 @@ int gpt_destroy(gpt_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->partials) (void)hipFree(c->partials);
     if (c->arena) (void)hipFree(c->arena);
+    if (c->sink) (void)hipFree(c->sink);
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
     return GPT_OK;
@@ -462,7 +465,7 @@ int gpt_gp_rfft2_lpdf_vjp(gpt_ctx* c, const double* y, int64_t y_bs, const doubl
     a.out_cov = grad_cov;
     a.out_lpdf = lpdf;
     a.min_eig = min_eig;
-    return run_lattice(c, OP_LPDF_VJP, a);
+    return run_lattice(c, grad_cov ? OP_LPDF_VJP : OP_LPDF_VJP_NOCOV, a);
 }
 
 int gpt_gp_inv_rfft2_vjp(gpt_ctx* c, const double* z, int64_t z_bs, const double* cov, int64_t cov_bs,
@@ -476,6 +479,10 @@ int gpt_gp_inv_rfft2_vjp(gpt_ctx* c, const double* z, int64_t z_bs, const double
     a.aux = fbar; a.aux_bs = fbar_bs;
     a.out = zbar;
     a.out_cov = covbar;
+    if (!covbar) {
+        if ((rc = ensure(c, c->sink, c->sink_bytes, sizeof(double) * (size_t)batch * H * (W / 2 + 1)))) return rc;
+        a.out_cov = c->sink;
+    }
     return run_lattice(c, OP_INV_VJP, a);
 }
 
@@ -491,6 +498,10 @@ int gpt_gp_rfft2_vjp(gpt_ctx* c, const double* y, int64_t y_bs, const double* lo
     a.aux = zbar; a.aux_bs = zbar_bs;
     a.out = ybar;
     a.out_cov = covbar;
+    if (!covbar) {
+        if ((rc = ensure(c, c->sink, c->sink_bytes, sizeof(double) * (size_t)batch * H * (W / 2 + 1)))) return rc;
+        a.out_cov = c->sink;
+    }
     return run_lattice(c, OP_FWD_VJP, a);
 }
 

@@ -28,15 +28,19 @@ enum GptOp : int {
     OP_LPDF_VJP = 5,     // value + d/dy + d/dcov (fused forward/backward)
     OP_INV_VJP = 6,      // VJP of OP_GP_INV_RFFT2: fbar -> zbar, covbar
     OP_FWD_VJP = 7,      // VJP of OP_GP_RFFT2: zbar -> ybar, covbar
-    OP_COUNT = 8
+    OP_LPDF_VJP_NOCOV = 8, // OP_LPDF_VJP without d/dcov (caller passed grad_cov == NULL)
+    OP_COUNT = 9
 };
+
+__host__ __device__ constexpr bool op_is_lpdf_vjp(int op) { return op == OP_LPDF_VJP || op == OP_LPDF_VJP_NOCOV; }
 
 __host__ __device__ constexpr bool op_has_fwd(int op) {
     return op == OP_RFFT2 || op == OP_GP_RFFT2 || op == OP_LPDF || op == OP_LPDF_VJP ||
-           op == OP_INV_VJP || op == OP_FWD_VJP;
+           op == OP_INV_VJP || op == OP_FWD_VJP || op == OP_LPDF_VJP_NOCOV;
 }
 __host__ __device__ constexpr bool op_has_inv(int op) {
-    return op == OP_INV_RFFT2 || op == OP_GP_INV_RFFT2 || op == OP_LPDF_VJP || op == OP_FWD_VJP;
+    return op == OP_INV_RFFT2 || op == OP_GP_INV_RFFT2 || op == OP_LPDF_VJP || op == OP_FWD_VJP ||
+           op == OP_LPDF_VJP_NOCOV;
 }
 
 // One line-FFT plan (any length): Stockham stages with radices r[0..ns).
@@ -142,9 +146,35 @@ __device__ __forceinline__ ZLayout make_layout(const LatArgs& a) {
 
 // Per-thread accumulators of the elementwise stage.
 struct EwAcc {
-    double sum; // log-density partial
-    double mn;  // min of n*c/2 seen
+    double sum;  // log-density partial (everything except the pair entries' log c)
+    double mn;   // min of n*c/2 seen
+    double mant; // sum over pair entries of log(c) is kept as log(mant) + ex * ln 2: one frexp and one
+    int ex;      // multiplication per entry instead of a 60-instruction fp64 log (and more accurate)
 };
+
+__device__ __forceinline__ void acc_init(EwAcc& acc) {
+    acc.sum = 0.0;
+    acc.mn = INFINITY;
+    acc.mant = 1.0;
+    acc.ex = 0;
+}
+// acc += log(c) for a pair entry, deferred.
+__device__ __forceinline__ void acc_log(EwAcc& acc, double c) {
+    acc.mant *= __builtin_amdgcn_frexp_mant(c);
+    acc.ex += __builtin_amdgcn_frexp_exp(c);
+}
+// Renormalise (call at least every ~900 entries: each factor is in [0.5, 1)).
+__device__ __forceinline__ void acc_renorm(EwAcc& acc) {
+    const int e = __builtin_amdgcn_frexp_exp(acc.mant);
+    acc.mant = __builtin_amdgcn_frexp_mant(acc.mant);
+    acc.ex += e;
+}
+// Fold the deferred logs into the running sum (sum -= sum of log c).
+__device__ __forceinline__ void acc_fold(EwAcc& acc) {
+    acc.sum -= log(acc.mant) + (double)acc.ex * 0.69314718055994530942;
+    acc.mant = 1.0;
+    acc.ex = 0;
+}
 
 // Per-lattice base pointers (workgroup-uniform: they live in SGPRs); elements are then addressed with
 // 32-bit offsets (H * W < 2^31 as in the reference, fft2.stan:15), one VGPR per address.
@@ -176,8 +206,8 @@ __device__ __forceinline__ EwPtrs make_ptrs(const LatArgs& a, int64_t b) {
 // whitened with s^2 = n c / 2 (fft2.stan:13-40, 67-68). F is the spectrum value on entry (ops with a
 // forward transform); the return value replaces it (ops with an inverse transform).
 template <int OP>
-__device__ __forceinline__ cplx ew_interior(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int i, int j,
-                                           cplx F, EwAcc& acc) {
+__device__ __forceinline__ cplx ew_interior_c(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int i, int j,
+                                             cplx F, double c, EwAcc& acc) {
     const double n = (double)a.H * (double)a.W;
     const unsigned ic = (unsigned)i * (unsigned)L.Wf + (unsigned)j; // offset into H x Wf arrays
     const unsigned iz = (unsigned)i * (unsigned)a.W;                // row offset into H x W arrays
@@ -189,7 +219,6 @@ __device__ __forceinline__ cplx ew_interior(const LatArgs& a, const ZLayout& L, 
     if (OP == OP_INV_RFFT2) {
         return P.cin[ic];
     }
-    const double c = P.cov[ic];
     acc.mn = fmin(acc.mn, 0.5 * n * c);
     if (OP == OP_GP_RFFT2) {
         const double inv_s = 1.0 / sqrt(0.5 * n * c);
@@ -198,13 +227,14 @@ __device__ __forceinline__ cplx ew_interior(const LatArgs& a, const ZLayout& L, 
     } else if (OP == OP_GP_INV_RFFT2) {
         const double s = sqrt(0.5 * n * c);
         ret = make_double2(P.x[iz + L.re_col(j)] * s, P.x[iz + L.im_col(j)] * s);
-    } else if (OP == OP_LPDF || OP == OP_LPDF_VJP) {
+    } else if (OP == OP_LPDF || op_is_lpdf_vjp(OP)) {
         const double f2 = fma(F.x, F.x, F.y * F.y);
         const double inv_c = 1.0 / c;
         const double q = f2 * inv_c / n; // |F|^2 / (n c)
-        acc.sum -= q + log(c);
-        if (OP == OP_LPDF_VJP) {
-            if (P.out_cov) P.out_cov[ic] = (q - 1.0) * inv_c;
+        acc.sum -= q;
+        acc_log(acc, c);
+        if (op_is_lpdf_vjp(OP)) {
+            if (OP == OP_LPDF_VJP) P.out_cov[ic] = (q - 1.0) * inv_c;
             ret = cscale(F, inv_c);
         }
     } else if (OP == OP_INV_VJP) {
@@ -214,18 +244,25 @@ __device__ __forceinline__ cplx ew_interior(const LatArgs& a, const ZLayout& L, 
         const double k2 = 2.0 / n;
         P.out[iz + L.re_col(j)] = k2 * s * F.x;
         P.out[iz + L.im_col(j)] = k2 * s * F.y;
-        if (P.out_cov) {
-            const double sbar = k2 * fma(pr, F.x, pi * F.y);
-            P.out_cov[ic] = sbar * s / (2.0 * c);
-        }
+        const double sbar = k2 * fma(pr, F.x, pi * F.y);
+        P.out_cov[ic] = sbar * s / (2.0 * c);
     } else if (OP == OP_FWD_VJP) {
         // F = rfft2(y - loc); Q = pack(zbar); returns Dh = Q / (2 s)
         const double s = sqrt(0.5 * n * c);
         const double qr = P.aux[iz + L.re_col(j)], qi = P.aux[iz + L.im_col(j)];
-        if (P.out_cov) P.out_cov[ic] = -fma(qr, F.x, qi * F.y) / (2.0 * c * s);
+        P.out_cov[ic] = -fma(qr, F.x, qi * F.y) / (2.0 * c * s);
         ret = make_double2(0.5 * qr / s, 0.5 * qi / s);
     }
     return ret;
+}
+
+// Same, loading c itself (ops without cov never touch the pointer).
+template <int OP>
+__device__ __forceinline__ cplx ew_interior(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int i, int j,
+                                           cplx F, EwAcc& acc) {
+    double c = 1.0;
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) c = P.cov[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
+    return ew_interior_c<OP>(a, L, P, i, j, F, c, acc);
 }
 
 // Elementwise stage, EDGE column j (j == 0 or, W even, j == W/2), row k in 0..H/2. FA is the value of
@@ -281,20 +318,20 @@ __device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, cons
             const double se = 0.5 * (sqrt(0.5 * n * c) + sqrt(0.5 * n * cm));
             ret = make_double2(P.x[zr] * se, P.x[zi] * se);
         }
-    } else if (OP == OP_LPDF || OP == OP_LPDF_VJP) {
+    } else if (OP == OP_LPDF || op_is_lpdf_vjp(OP)) {
         const double inv_c = 1.0 / c;
         if (real_pt) {
             const double q = FA.x * FA.x * inv_c / n;
             acc.sum -= 0.5 * (q + log(c));
-            if (OP == OP_LPDF_VJP) {
-                if (P.out_cov) P.out_cov[ck] = 0.5 * (q - 1.0) * inv_c;
+            if (op_is_lpdf_vjp(OP)) {
+                if (OP == OP_LPDF_VJP) P.out_cov[ck] = 0.5 * (q - 1.0) * inv_c;
                 ret = make_double2(FA.x * inv_c, 0.0);
             }
         } else {
             const double q = fma(FA.x, FA.x, FA.y * FA.y) * inv_c / n;
             acc.sum -= q + log(c);
-            if (OP == OP_LPDF_VJP) {
-                if (P.out_cov) {
+            if (op_is_lpdf_vjp(OP)) {
+                if (OP == OP_LPDF_VJP) {
                     P.out_cov[ck] = (q - 1.0) * inv_c;
                     P.out_cov[cm_] = 0.0;
                 }
@@ -306,34 +343,28 @@ __device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, cons
         if (real_pt) {
             const double s = sqrt(n * c);
             P.out[zr] = k1 * s * FA.x;
-            if (P.out_cov) {
-                const double sbar = k1 * P.x[zr] * FA.x;
-                P.out_cov[ck] = sbar * s / (2.0 * c);
-            }
+            const double sbar = k1 * P.x[zr] * FA.x;
+            P.out_cov[ck] = sbar * s / (2.0 * c);
         } else {
             const double s = sqrt(0.5 * n * c), sm = sqrt(0.5 * n * cm);
             const double pr = P.x[zr], pi = P.x[zi];
             P.out[zr] = k1 * (s + sm) * FA.x;
             P.out[zi] = k1 * (s + sm) * FA.y;
-            if (P.out_cov) {
-                const double sbar = k1 * fma(pr, FA.x, pi * FA.y);
-                P.out_cov[ck] = sbar * s / (2.0 * c);
-                P.out_cov[cm_] = sbar * sm / (2.0 * cm);
-            }
+            const double sbar = k1 * fma(pr, FA.x, pi * FA.y);
+            P.out_cov[ck] = sbar * s / (2.0 * c);
+            P.out_cov[cm_] = sbar * sm / (2.0 * cm);
         }
     } else if (OP == OP_FWD_VJP) {
         if (real_pt) {
             const double s = sqrt(n * c);
             const double qr = P.aux[zr];
-            if (P.out_cov) P.out_cov[ck] = -(qr * FA.x) / (2.0 * c * s);
+            P.out_cov[ck] = -(qr * FA.x) / (2.0 * c * s);
             ret = make_double2(qr / s, 0.0);
         } else {
             const double s = sqrt(0.5 * n * c);
             const double qr = P.aux[zr], qi = P.aux[zi];
-            if (P.out_cov) {
-                P.out_cov[ck] = -fma(qr, FA.x, qi * FA.y) / (2.0 * c * s);
-                P.out_cov[cm_] = 0.0;
-            }
+            P.out_cov[ck] = -fma(qr, FA.x, qi * FA.y) / (2.0 * c * s);
+            P.out_cov[cm_] = 0.0;
             ret = make_double2(0.5 * qr / s, 0.5 * qi / s);
         }
     }
@@ -372,7 +403,7 @@ __device__ __forceinline__ double out_transform(const LatArgs& a, int64_t b, int
         const double l = a.loc ? a.loc[b * a.loc_bs + (int64_t)i * a.W + j] : 0.0;
         return v / n + l;
     }
-    if (OP == OP_LPDF_VJP) return -v / n;
+    if (op_is_lpdf_vjp(OP)) return -v / n;
     return v;
 }
 

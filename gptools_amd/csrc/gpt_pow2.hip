@@ -50,7 +50,7 @@ hipError_t gpt_launch_pow2(int op, const LatArgs& a, cplx* ws, double* partials,
     mark(2);
     if (op != OP_RFFT2 && op != OP_INV_RFFT2) {
         const int nblk = gpt_pow2_col_blocks(a.H, a.W);
-        const bool lp = (op == OP_LPDF || op == OP_LPDF_VJP);
+        const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op));
         e = gpt_launch_finalize(partials, nblk, a.batch, 1, -0.5 * n * 1.8378770664093454836,
                                 lp ? a.out_lpdf : nullptr, a.min_eig, st);
         if (e != hipSuccess) return e;
@@ -61,7 +61,7 @@ hipError_t gpt_launch_pow2(int op, const LatArgs& a, cplx* ws, double* partials,
         int add_loc = 0;
         if (op == OP_INV_RFFT2) alpha = 1.0 / n;
         else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
-        else if (op == OP_LPDF_VJP) alpha = -1.0 / n;
+        else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
         e = by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, st); });
     }
     mark(4);

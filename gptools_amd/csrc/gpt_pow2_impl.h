@@ -24,6 +24,12 @@ namespace pow2 {
 constexpr int E = 16;
 constexpr int COL_SKEW = 8;
 
+// Timing-only ablation builds (make ABLATE=<bits>): 1 = no butterflies, 2 = no LDS exchanges,
+// 4 = no elementwise stage. Results are wrong by construction; never shipped.
+#ifndef GPT_ABLATE
+#define GPT_ABLATE 0
+#endif
+
 __device__ __forceinline__ int phys(int o) { return o ^ ((o >> 4) & 15); }
 
 template <bool INV> __device__ __forceinline__ cplx tw_dir(cplx w) {
@@ -116,22 +122,45 @@ template <bool INV> struct Bfly<16, INV> {
     }
 };
 
-// One Stockham stage on registers: U = E/R butterflies of radix R per thread.
+// One Stockham stage on registers: U = E/R butterflies of radix R per thread. The R-1 twiddles of a
+// butterfly are w^q, q = 1..R-1, of ONE table entry w = w_N^{k * N/(NS*R)}: one L2 load plus a power chain
+// (<= 15 multiplications, relative error <= ~2e-15) instead of 15 dependent table look-ups per stage.
 template <int N, int R, int NS, bool INV>
 __device__ __forceinline__ void stage_bfly(cplx (&v)[E], int t, const cplx* __restrict__ tw) {
     constexpr int T = N / E, U = E / R;
+    if (GPT_ABLATE & 1) return;
+    cplx w1[U];
+    if (NS > 1) {
+        constexpr int tstep = N / (NS * R);
+#pragma unroll
+        for (int u = 0; u < U; ++u) w1[u] = tw_dir<INV>(tw[((t + T * u) & (NS - 1)) * tstep]);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         cplx x[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) x[q] = v[u + q * U];
         if (NS > 1) {
-            constexpr int tstep = N / (NS * R);
-            const int k = (t + T * u) & (NS - 1);
+            // powers w^1 .. w^(R-1) as a shallow tree: w2 = w1^2, w3 = w2 w1, w4 = w2^2, then w^(4g + r) =
+            // (w4)^g * w^r: depth <= 5 multiplications, relative error of a few ulp
+            const cplx wa = w1[u];
+            x[1] = cmul(x[1], wa);
+            if (R > 2) {
+                const cplx wb = cmul(wa, wa), wc = cmul(wb, wa);
+                x[2] = cmul(x[2], wb);
+                x[3] = cmul(x[3], wc);
+                if (R > 4) {
+                    const cplx w4 = cmul(wb, wb);
+                    cplx base = w4;
 #pragma unroll
-            for (int q = 1; q < R; ++q) {
-                const cplx w = tw_dir<INV>(tw[(q * k * tstep) & (N - 1)]);
-                x[q] = cmul(x[q], w);
+                    for (int g = 1; g < R / 4; ++g) {
+                        x[4 * g] = cmul(x[4 * g], base);
+                        x[4 * g + 1] = cmul(x[4 * g + 1], cmul(base, wa));
+                        x[4 * g + 2] = cmul(x[4 * g + 2], cmul(base, wb));
+                        x[4 * g + 3] = cmul(x[4 * g + 3], cmul(base, wc));
+                        if (g + 1 < R / 4) base = cmul(base, w4);
+                    }
+                }
             }
         }
         Bfly<R, INV>::run(x);
@@ -141,25 +170,40 @@ __device__ __forceinline__ void stage_bfly(cplx (&v)[E], int t, const cplx* __re
 }
 
 // Exchange after a (non-final) stage: scatter the butterfly outputs to their Stockham positions, gather
-// back the elements t + T*m the next stage needs.
+// back the elements t + T*m the next stage needs. Real and imaginary parts travel separately, so a line
+// needs N * 8 bytes of LDS (32 KB for N = 4096): twice the workgroups fit a CU.
 template <int N, int R, int NS>
-__device__ __forceinline__ void exchange(cplx (&v)[E], int t, cplx* lds) {
+__device__ __forceinline__ void exchange(cplx (&v)[E], int t, double* lds) {
     constexpr int T = N / E, U = E / R;
-    __syncthreads(); // everyone is done reading the previous contents of this LDS region
+    if (GPT_ABLATE & 2) return;
+    int o0[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int j = t + T * u;
-        const int o0 = (j / NS) * NS * R + (j & (NS - 1));
-#pragma unroll
-        for (int p = 0; p < R; ++p) lds[phys(o0 + p * NS)] = v[u + p * U];
+        o0[u] = (j / NS) * NS * R + (j & (NS - 1));
     }
+    __syncthreads(); // everyone is done reading the previous contents of this LDS region
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < R; ++p) lds[phys(o0[u] + p * NS)] = v[u + p * U].x;
+    __syncthreads();
+    // (t + T m) >> 4 & 15 does not depend on m when T is a multiple of 256: one swizzled base + offsets
+    const int rb = phys(t);
+#pragma unroll
+    for (int m = 0; m < E; ++m) v[m].x = lds[(T % 256 == 0) ? rb + T * m : phys(t + T * m)];
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < E; ++m) v[m] = lds[phys(t + T * m)];
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < R; ++p) lds[phys(o0[u] + p * NS)] = v[u + p * U].y;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E; ++m) v[m].y = lds[(T % 256 == 0) ? rb + T * m : phys(t + T * m)];
 }
 
 template <int N, int NS, bool INV>
-__device__ __forceinline__ void fft_rec(cplx (&v)[E], int t, cplx* lds, const cplx* __restrict__ tw) {
+__device__ __forceinline__ void fft_rec(cplx (&v)[E], int t, double* lds, const cplx* __restrict__ tw) {
     constexpr int REM = N / NS;
     constexpr int R = REM >= 16 ? 16 : REM;
     stage_bfly<N, R, NS, INV>(v, t, tw);
@@ -169,9 +213,9 @@ __device__ __forceinline__ void fft_rec(cplx (&v)[E], int t, cplx* lds, const cp
     }
 }
 
-// In: v[m] = x[t + T m]. Out: v[m] = X[t + T m] (natural order). `lds` is this line's N-element region.
+// In: v[m] = x[t + T m]. Out: v[m] = X[t + T m] (natural order). `lds` is this line's region of N doubles.
 template <int N, bool INV>
-__device__ __forceinline__ void fft_regs(cplx (&v)[E], int t, cplx* lds, const cplx* __restrict__ tw) {
+__device__ __forceinline__ void fft_regs(cplx (&v)[E], int t, double* lds, const cplx* __restrict__ tw) {
     fft_rec<N, 1, INV>(v, t, lds, tw);
 }
 
@@ -181,7 +225,10 @@ template <int N> struct Geo {
     static constexpr int T = N / E;                      // threads per line
     static constexpr int ROW_THREADS = T < 256 ? 256 : T; // row kernels: >= 256 threads
     static constexpr int ROW_LINES = ROW_THREADS / T;     // row pairs per workgroup
-    static constexpr int COL_THREADS = T < 512 ? 512 : T; // column kernel
+#ifndef GPT_COL_THREADS
+#define GPT_COL_THREADS 1024
+#endif
+    static constexpr int COL_THREADS = T < GPT_COL_THREADS ? GPT_COL_THREADS : T; // column kernel
     static constexpr int TC = COL_THREADS / T;            // adjacent packed columns per workgroup
 };
 
@@ -193,7 +240,7 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int T = Geo<W>::T, LINES = Geo<W>::ROW_LINES;
     const int line = threadIdx.x / T, t = threadIdx.x - line * T;
-    cplx* lds = reinterpret_cast<cplx*>(smem) + (size_t)line * W;
+    double* lds = reinterpret_cast<double*>(smem) + (size_t)line * W;
     const int64_t b = blockIdx.y;
     const int H = a.H;
     const int npairs = H / 2;
@@ -216,11 +263,26 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
         }
     }
     fft_regs<W, false>(v, t, lds, a.pw.tw);
-    // split the two rows: need Z[j] (own registers) and Z[W - j] (through LDS)
+    // split the two rows: need Z[j] (own registers) and Z[W - j] (through LDS, re then im)
+    cplx zc[E / 2];
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m];
+    for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m].x;
     __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E / 2; ++m) {
+        const int j = t + T * m;
+        zc[m].x = lds[phys(j == 0 ? 0 : W - j)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m].y;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E / 2; ++m) {
+        const int j = t + T * m;
+        zc[m].y = lds[phys(j == 0 ? 0 : W - j)];
+    }
     if (!active) return;
     cplx* s0 = ws + ((int64_t)b * H + 2 * rr) * wstride;
     cplx* s1 = s0 + wstride;
@@ -233,9 +295,8 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
             s0[0] = make_double2(z.x, zn.x);
             s1[0] = make_double2(z.y, zn.y);
         } else {
-            const cplx zc = lds[phys(W - j)];
-            s0[j] = make_double2(0.5 * (z.x + zc.x), 0.5 * (z.y - zc.y));
-            s1[j] = make_double2(0.5 * (z.y + zc.y), -0.5 * (z.x - zc.x));
+            s0[j] = make_double2(0.5 * (z.x + zc[m].x), 0.5 * (z.y - zc[m].y));
+            s1[j] = make_double2(0.5 * (z.y + zc[m].y), -0.5 * (z.x - zc[m].x));
         }
     }
 }
@@ -248,7 +309,7 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int T = Geo<W>::T, LINES = Geo<W>::ROW_LINES;
     const int line = threadIdx.x / T, t = threadIdx.x - line * T;
-    cplx* lds = reinterpret_cast<cplx*>(smem) + (size_t)line * W;
+    double* lds = reinterpret_cast<double*>(smem) + (size_t)line * W;
     const int64_t b = blockIdx.y;
     const int H = a.H;
     const int r = blockIdx.x * LINES + line;
@@ -298,14 +359,15 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
 
 // pass B --------------------------------------------------------------------------------------------
 template <int H, int OP>
-__global__ void __launch_bounds__(Geo<H>::COL_THREADS) col_kernel(LatArgs a, cplx* __restrict__ ws, int wstride,
+__global__ void __launch_bounds__(Geo<H>::COL_THREADS, (Geo<H>::COL_THREADS >= 1024 ? 4 : 4)) col_kernel(LatArgs a, cplx* __restrict__ ws, int wstride,
                                                                   double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int T = Geo<H>::T, TC = Geo<H>::TC;
     const int c = threadIdx.x % TC, t = threadIdx.x / TC;
     // adjacent columns' regions are skewed by 8 elements (128 B): the lanes of one LDS lane group alternate
     // between columns, and an unskewed region start would put them on the same banks (2-way conflict)
-    cplx* lds = reinterpret_cast<cplx*>(smem) + (size_t)c * (H + COL_SKEW);
+    double* lds = reinterpret_cast<double*>(smem) + (size_t)c * (H + COL_SKEW);
+    cplx* lds0 = reinterpret_cast<cplx*>(smem);    // whole buffer as one complex column (packed column 0)
     double* red = reinterpret_cast<double*>(smem); // reused after the FFTs are done with LDS
     const int64_t b = blockIdx.y;
     // XCD-aware mapping. Workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 labels the XCD),
@@ -332,53 +394,48 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS) col_kernel(LatArgs a, cpl
         for (int m = 0; m < E; ++m) v[m] = make_double2(0.0, 0.0);
     }
     EwAcc acc;
-    acc.sum = 0.0;
-    acc.mn = INFINITY;
-    if (j0 == 0) { // workgroup-uniform: this workgroup owns the packed column 0
+    acc_init(acc);
+    constexpr bool NEEDS_COV = (OP != OP_RFFT2 && OP != OP_INV_RFFT2);
+    const bool own0 = (j0 == 0); // workgroup-uniform: this workgroup owns the packed column 0
+    if (own0) {
+        // Packed column 0 (DC + i*Nyquist): rows k and H-k must meet, so the column goes through LDS and
+        // is processed by a ROLLED loop (few registers, little code; one column out of W/2).
         __syncthreads();
         if (c == 0) {
 #pragma unroll
-            for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m];
+            for (int m = 0; m < E; ++m) lds0[phys(t + T * m)] = v[m];
         }
         __syncthreads();
-        if (c == 0) {
-#pragma unroll
-            for (int m = 0; m <= E / 2; ++m) {
-                const int k = t + T * m;
-                if (k <= H / 2) {
-                    const bool self = (k == 0) || (k == H / 2);
-                    cplx Zk = v[m];
-                    cplx Zm = self ? Zk : lds[phys(H - k)];
-                    ew_packed0<OP>(a, L, P, k, Zk, Zm, acc);
-                    if (op_has_inv(OP)) {
-                        v[m] = Zk;
-                        if (!self) lds[phys(H - k)] = Zm;
-                    }
-                }
+#pragma unroll 1
+        for (int k = threadIdx.x; k <= H / 2; k += Geo<H>::COL_THREADS) {
+            const bool self = (k == 0) || (k == H / 2);
+            cplx Zk = lds0[phys(k)];
+            cplx Zm = self ? Zk : lds0[phys(H - k)];
+            ew_packed0<OP>(a, L, P, k, Zk, Zm, acc);
+            if (op_has_inv(OP)) {
+                lds0[phys(k)] = Zk;
+                if (!self) lds0[phys(H - k)] = Zm;
             }
         }
         __syncthreads();
         if (c == 0 && op_has_inv(OP)) {
 #pragma unroll
-            for (int m = E / 2; m < E; ++m) {
-                const int k = t + T * m;
-                if (k > H / 2) v[m] = lds[phys(k)];
-            }
+            for (int m = 0; m < E; ++m) v[m] = lds0[phys(t + T * m)];
         }
-        if (c != 0) {
-#pragma unroll
-            for (int m = 0; m < E; ++m) {
-                v[m] = ew_interior<OP>(a, L, P, t + T * m, jp, v[m], acc);
-                if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < E; ++m) {
-            v[m] = ew_interior<OP>(a, L, P, t + T * m, jp, v[m], acc);
-            if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
+        __syncthreads();
     }
+    if (!(own0 && c == 0) && !(GPT_ABLATE & 4)) {
+        // interior columns: all 16 cov values of this thread are requested before any is used
+        double cv[E];
+        if (NEEDS_COV) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) cv[m] = P.cov[(unsigned)(t + T * m) * (unsigned)L.Wf + (unsigned)jp];
+        }
+#pragma unroll
+        for (int m = 0; m < E; ++m)
+            v[m] = ew_interior_c<OP>(a, L, P, t + T * m, jp, v[m], NEEDS_COV ? cv[m] : 1.0, acc);
+    }
+    acc_fold(acc);
     __builtin_amdgcn_sched_barrier(0);
     if (op_has_inv(OP)) {
         // Launder the table pointer: otherwise the compiler keeps all 30 twiddles of the forward transform
@@ -387,7 +444,9 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS) col_kernel(LatArgs a, cpl
         const cplx* tw_inv = a.ph.tw;
         int t_inv = t;
         asm volatile("" : "+s"(tw_inv));
-        asm volatile("" : "+v"(t_inv));
+        // ... tied to a value the elementwise stage produced, so that nothing of the inverse transform
+        // (addresses, twiddle power chains) is scheduled above it.
+        asm volatile("" : "+v"(t_inv), "+v"(v[0].x));
         fft_regs<H, true>(v, t_inv, lds, tw_inv);
 #pragma unroll
         for (int m = 0; m < E; ++m) wsb[(unsigned)(t_inv + T * m) * (unsigned)wstride + (unsigned)jp] = v[m];

@@ -8,6 +8,11 @@
 namespace pow2 {
 
 namespace {
+// split exchange: TC regions of (H + skew) doubles; the packed column 0 needs H complex values once
+template <int H> constexpr size_t col_lds_bytes() {
+    const size_t a = (size_t)Geo<H>::TC * (H + COL_SKEW) * sizeof(double), b = (size_t)H * sizeof(cplx);
+    return a > b ? a : b;
+}
 template <typename K> hipError_t raise_lds(K kernel, size_t lds) {
     if (lds <= 64 * 1024) return hipSuccess;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -18,7 +23,7 @@ template <typename K> hipError_t raise_lds(K kernel, size_t lds) {
 template <>
 hipError_t Launch<GPT_N>::row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, hipStream_t st) {
     constexpr int W = GPT_N;
-    const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(cplx);
+    const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(double);
     hipError_t e = raise_lds(row_fwd_kernel<W>, lds);
     if (e != hipSuccess) return e;
     const int npairs = a.H / 2;
@@ -31,7 +36,7 @@ template <>
 hipError_t Launch<GPT_N>::row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
                                   hipStream_t st) {
     constexpr int W = GPT_N;
-    const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(cplx);
+    const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(double);
     hipError_t e = raise_lds(row_inv_kernel<W>, lds);
     if (e != hipSuccess) return e;
     const int npairs = a.H / 2;
@@ -43,7 +48,7 @@ hipError_t Launch<GPT_N>::row_inv(const LatArgs& a, double alpha, int add_loc, c
 template <int OP>
 static hipError_t col_t(const LatArgs& a, cplx* ws, int wstride, double* partials, hipStream_t st) {
     constexpr int H = GPT_N;
-    const size_t lds = (size_t)Geo<H>::TC * (H + COL_SKEW) * sizeof(cplx);
+    const size_t lds = col_lds_bytes<H>();
     hipError_t e = raise_lds(col_kernel<H, OP>, lds);
     if (e != hipSuccess) return e;
     dim3 grid((a.W / 2) / Geo<H>::TC, (unsigned)a.batch);
@@ -62,6 +67,7 @@ hipError_t Launch<GPT_N>::col(int op, const LatArgs& a, cplx* ws, int wstride, d
     case OP_LPDF_VJP: return col_t<OP_LPDF_VJP>(a, ws, wstride, partials, st);
     case OP_INV_VJP: return col_t<OP_INV_VJP>(a, ws, wstride, partials, st);
     case OP_FWD_VJP: return col_t<OP_FWD_VJP>(a, ws, wstride, partials, st);
+    case OP_LPDF_VJP_NOCOV: return col_t<OP_LPDF_VJP_NOCOV>(a, ws, wstride, partials, st);
     default: return hipErrorInvalidValue;
     }
 }

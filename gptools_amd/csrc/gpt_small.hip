@@ -127,14 +127,15 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
 
     // elementwise stage on S = cur
     EwAcc acc;
-    acc.sum = 0.0;
-    acc.mn = INFINITY;
+    acc_init(acc);
     for (int w = threadIdx.x; w < H * L.wc; w += blockDim.x) {
         const int i = w / L.wc, j = 1 + (w - i * L.wc);
         const cplx F = cur[i * sS + j];
         const cplx G = ew_interior<OP>(a, L, P, i, j, F, acc);
         if (op_has_inv(OP)) cur[i * sS + j] = G;
+        acc_renorm(acc);
     }
+    acc_fold(acc);
     for (int k = threadIdx.x; k <= H / 2; k += blockDim.x) {
         const int km = (H - k) % H;
         cplx Zk = cur[k * sS], Zm = cur[km * sS];
@@ -144,12 +145,11 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
             if (km != k) cur[km * sS] = Zm;
         }
     }
-    if (OP == OP_LPDF || OP == OP_LPDF_VJP || OP == OP_GP_RFFT2 || OP == OP_GP_INV_RFFT2 ||
-        OP == OP_INV_VJP || OP == OP_FWD_VJP) {
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
         double s = acc.sum, m = acc.mn;
         block_sum_min(s, m, red);
         if (threadIdx.x == 0) {
-            if ((OP == OP_LPDF || OP == OP_LPDF_VJP) && a.out_lpdf)
+            if ((OP == OP_LPDF || op_is_lpdf_vjp(OP)) && a.out_lpdf)
                 a.out_lpdf[b] = s - 0.5 * (double)H * (double)W * 1.8378770664093454836;
             if (a.min_eig) a.min_eig[b] = m;
         }
@@ -241,6 +241,7 @@ hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st) {
     case OP_LPDF_VJP: return launch_small_t<OP_LPDF_VJP>(a, cap, sS, nthreads, lds, st);
     case OP_INV_VJP: return launch_small_t<OP_INV_VJP>(a, cap, sS, nthreads, lds, st);
     case OP_FWD_VJP: return launch_small_t<OP_FWD_VJP>(a, cap, sS, nthreads, lds, st);
+    case OP_LPDF_VJP_NOCOV: return launch_small_t<OP_LPDF_VJP_NOCOV>(a, cap, sS, nthreads, lds, st);
     default: return hipErrorInvalidValue;
     }
 }
