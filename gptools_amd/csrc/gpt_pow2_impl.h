@@ -23,6 +23,13 @@ namespace pow2 {
 
 constexpr int E = 16;
 constexpr int COL_SKEW = 8;
+#ifndef GPT_COL_WGS_PER_CU
+#define GPT_COL_WGS_PER_CU 1
+#endif
+
+// Scheduling fence: hipcc's scheduler otherwise interleaves the whole (fully unrolled) transform for ILP and
+// stretches live ranges until the 16-element register tile spills; program order is in-place.
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // Timing-only ablation builds (make ABLATE=<bits>): 1 = no butterflies, 2 = no LDS exchanges,
 // 4 = no elementwise stage. Results are wrong by construction; never shipped.
@@ -90,7 +97,10 @@ template <bool INV> struct Bfly<16, INV> {
         constexpr double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173; // cos, sin(pi/8)
         constexpr double h = 0.70710678118654752440;
 #pragma unroll
-        for (int q2 = 0; q2 < 4; ++q2) bfly4<INV>(x[q2], x[4 + q2], x[8 + q2], x[12 + q2]);
+        for (int q2 = 0; q2 < 4; ++q2) {
+            bfly4<INV>(x[q2], x[4 + q2], x[8 + q2], x[12 + q2]);
+            if (q2 & 1) SCHED_FENCE();
+        }
         // now x[4 p1 + q2] = y[p1][q2]; twiddle by w16^{q2 p1} = exp(-+ 2 pi i q2 p1 / 16)
         auto tw = [](cplx a, double c, double s) -> cplx { // a * (c - i s) forward, a * (c + i s) inverse
             return INV ? make_double2(a.x * c - a.y * s, a.y * c + a.x * s)
@@ -108,8 +118,12 @@ template <bool INV> struct Bfly<16, INV> {
         x[13] = tw(x[13], s1, c1);
         x[14] = tw(x[14], -h, h);
         x[15] = tw(x[15], -c1, -s1);
+        SCHED_FENCE();
 #pragma unroll
-        for (int p1 = 0; p1 < 4; ++p1) bfly4<INV>(x[4 * p1], x[4 * p1 + 1], x[4 * p1 + 2], x[4 * p1 + 3]);
+        for (int p1 = 0; p1 < 4; ++p1) {
+            bfly4<INV>(x[4 * p1], x[4 * p1 + 1], x[4 * p1 + 2], x[4 * p1 + 3]);
+            if (p1 & 1) SCHED_FENCE();
+        }
         // x[4 p1 + p2] = X[p1 + 4 p2] -> transpose the 4 x 4 register tile
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -122,19 +136,41 @@ template <bool INV> struct Bfly<16, INV> {
     }
 };
 
-// One Stockham stage on registers: U = E/R butterflies of radix R per thread. The R-1 twiddles of a
-// butterfly are w^q, q = 1..R-1, of ONE table entry w = w_N^{k * N/(NS*R)}: one L2 load plus a power chain
-// (<= 15 multiplications, relative error <= ~2e-15) instead of 15 dependent table look-ups per stage.
-template <int N, int R, int NS, bool INV>
-__device__ __forceinline__ void stage_bfly(cplx (&v)[E], int t, const cplx* __restrict__ tw) {
+// Twiddle bases. Stage s (radix R, NS = product of the earlier radices, NS > 1) multiplies input q of
+// butterfly u by w^q with w = w_N^{((t + T u) mod NS) * N/(NS R)}: these bases depend on the thread only,
+// so a kernel loads them ONCE (NPRE table look-ups) and no transform issues a global load afterwards --
+// which also keeps the transforms from waiting on outstanding prefetches (vmcnt retires in order).
+template <int N> constexpr int tw_npre() {
+    int cnt = 0;
+    for (int ns = 1; ns < N;) {
+        const int r = (N / ns) >= 16 ? 16 : (N / ns);
+        if (ns > 1) cnt += E / r;
+        ns *= r;
+    }
+    return cnt;
+}
+template <int N, int NS, int IDX>
+__device__ __forceinline__ void tw_load_rec(cplx* w, const cplx* __restrict__ tw, int t) {
+    constexpr int REM = N / NS;
+    constexpr int R = REM >= 16 ? 16 : REM;
     constexpr int T = N / E, U = E / R;
-    if (GPT_ABLATE & 1) return;
-    cplx w1[U];
-    if (NS > 1) {
+    if constexpr (NS > 1) {
         constexpr int tstep = N / (NS * R);
 #pragma unroll
-        for (int u = 0; u < U; ++u) w1[u] = tw_dir<INV>(tw[((t + T * u) & (NS - 1)) * tstep]);
+        for (int u = 0; u < U; ++u) w[IDX + u] = tw[((t + T * u) & (NS - 1)) * tstep];
     }
+    if constexpr (NS * R < N) tw_load_rec<N, NS * R, IDX + (NS > 1 ? U : 0)>(w, tw, t);
+}
+template <int N> __device__ __forceinline__ void tw_load(cplx* w, const cplx* __restrict__ tw, int t) {
+    tw_load_rec<N, 1, 0>(w, tw, t);
+}
+
+// One Stockham stage on registers: U = E/R butterflies of radix R per thread. The R-1 twiddles of a
+// butterfly are powers of its base (a shallow multiplication tree, relative error of a few ulp).
+template <int N, int R, int NS, bool INV>
+__device__ __forceinline__ void stage_bfly(cplx (&v)[E], const cplx* w1) {
+    constexpr int U = E / R;
+    if (GPT_ABLATE & 1) return;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         cplx x[R];
@@ -143,7 +179,7 @@ __device__ __forceinline__ void stage_bfly(cplx (&v)[E], int t, const cplx* __re
         if (NS > 1) {
             // powers w^1 .. w^(R-1) as a shallow tree: w2 = w1^2, w3 = w2 w1, w4 = w2^2, then w^(4g + r) =
             // (w4)^g * w^r: depth <= 5 multiplications, relative error of a few ulp
-            const cplx wa = w1[u];
+            const cplx wa = tw_dir<INV>(w1[u]);
             x[1] = cmul(x[1], wa);
             if (R > 2) {
                 const cplx wb = cmul(wa, wa), wc = cmul(wb, wa);
@@ -154,6 +190,7 @@ __device__ __forceinline__ void stage_bfly(cplx (&v)[E], int t, const cplx* __re
                     cplx base = w4;
 #pragma unroll
                     for (int g = 1; g < R / 4; ++g) {
+                        SCHED_FENCE();
                         x[4 * g] = cmul(x[4 * g], base);
                         x[4 * g + 1] = cmul(x[4 * g + 1], cmul(base, wa));
                         x[4 * g + 2] = cmul(x[4 * g + 2], cmul(base, wb));
@@ -163,6 +200,7 @@ __device__ __forceinline__ void stage_bfly(cplx (&v)[E], int t, const cplx* __re
                 }
             }
         }
+        SCHED_FENCE();
         Bfly<R, INV>::run(x);
 #pragma unroll
         for (int p = 0; p < R; ++p) v[u + p * U] = x[p];
@@ -202,21 +240,23 @@ __device__ __forceinline__ void exchange(cplx (&v)[E], int t, double* lds) {
     for (int m = 0; m < E; ++m) v[m].y = lds[(T % 256 == 0) ? rb + T * m : phys(t + T * m)];
 }
 
-template <int N, int NS, bool INV>
-__device__ __forceinline__ void fft_rec(cplx (&v)[E], int t, double* lds, const cplx* __restrict__ tw) {
+template <int N, int NS, int IDX, bool INV>
+__device__ __forceinline__ void fft_rec(cplx (&v)[E], int t, double* lds, const cplx* wpre) {
     constexpr int REM = N / NS;
     constexpr int R = REM >= 16 ? 16 : REM;
-    stage_bfly<N, R, NS, INV>(v, t, tw);
+    constexpr int U = E / R;
+    stage_bfly<N, R, NS, INV>(v, wpre + IDX);
     if constexpr (NS * R < N) {
         exchange<N, R, NS>(v, t, lds);
-        fft_rec<N, NS * R, INV>(v, t, lds, tw);
+        fft_rec<N, NS * R, IDX + (NS > 1 ? U : 0), INV>(v, t, lds, wpre);
     }
 }
 
-// In: v[m] = x[t + T m]. Out: v[m] = X[t + T m] (natural order). `lds` is this line's region of N doubles.
+// In: v[m] = x[t + T m]. Out: v[m] = X[t + T m] (natural order). `lds` is this line's region of N doubles,
+// `wpre` the thread's twiddle bases (tw_load).
 template <int N, bool INV>
-__device__ __forceinline__ void fft_regs(cplx (&v)[E], int t, double* lds, const cplx* __restrict__ tw) {
-    fft_rec<N, 1, INV>(v, t, lds, tw);
+__device__ __forceinline__ void fft_regs(cplx (&v)[E], int t, double* lds, const cplx* wpre) {
+    fft_rec<N, 1, 0, INV>(v, t, lds, wpre);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -226,7 +266,7 @@ template <int N> struct Geo {
     static constexpr int ROW_THREADS = T < 256 ? 256 : T; // row kernels: >= 256 threads
     static constexpr int ROW_LINES = ROW_THREADS / T;     // row pairs per workgroup
 #ifndef GPT_COL_THREADS
-#define GPT_COL_THREADS 1024
+#define GPT_COL_THREADS 512
 #endif
     static constexpr int COL_THREADS = T < GPT_COL_THREADS ? GPT_COL_THREADS : T; // column kernel
     static constexpr int TC = COL_THREADS / T;            // adjacent packed columns per workgroup
@@ -250,6 +290,8 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
     const double* src = in_mode == 2 ? a.aux + b * a.aux_bs : a.x + b * a.x_bs;
     const double* r0 = src + (int64_t)(2 * rr) * W;
     const double* r1 = r0 + W;
+    cplx wpre[tw_npre<W>()];
+    tw_load<W>(wpre, a.pw.tw, t);
     cplx v[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) v[m] = make_double2(r0[t + T * m], r1[t + T * m]);
@@ -262,7 +304,7 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
             v[m].y -= l1[t + T * m];
         }
     }
-    fft_regs<W, false>(v, t, lds, a.pw.tw);
+    fft_regs<W, false>(v, t, lds, wpre);
     // split the two rows: need Z[j] (own registers) and Z[W - j] (through LDS, re then im)
     cplx zc[E / 2];
     __syncthreads();
@@ -317,6 +359,8 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
     const int rr = active ? r : 0;
     const cplx* s0 = ws + ((int64_t)b * H + 2 * rr) * wstride;
     const cplx* s1 = s0 + wstride;
+    cplx wpre[tw_npre<W>()];
+    tw_load<W>(wpre, a.pw.tw, t);
     cplx v[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) {
@@ -336,7 +380,7 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
             }
         }
     }
-    fft_regs<W, true>(v, t, lds, a.pw.tw);
+    fft_regs<W, true>(v, t, lds, wpre);
     if (!active) return;
     double* o0 = a.out + b * (int64_t)H * W + (int64_t)(2 * rr) * W;
     double* o1 = o0 + W;
@@ -358,104 +402,140 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
 }
 
 // pass B --------------------------------------------------------------------------------------------
+// Persistent: a workgroup walks over several column tiles (TC adjacent packed columns each) and requests
+// the NEXT tile's spectrum and cov values before it transforms the current one, so HBM / Infinity-Cache
+// traffic overlaps the arithmetic inside one workgroup (the transforms themselves issue no global loads).
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 labels the XCD),
+// and 8 / TC neighbouring tiles read pieces of the SAME 128-byte lines of the spectrum, of cov and of
+// d/dcov. Each XCD gets a contiguous range of tiles, walked in step by its workgroups, so the sharers meet
+// in one L2 (speed only, never correctness).
 template <int H, int OP>
-__global__ void __launch_bounds__(Geo<H>::COL_THREADS, (Geo<H>::COL_THREADS >= 1024 ? 4 : 4)) col_kernel(LatArgs a, cplx* __restrict__ ws, int wstride,
-                                                                  double* __restrict__ partials) {
+__global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, cplx* __restrict__ ws, int wstride,
+                                                                     double* __restrict__ partials, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int T = Geo<H>::T, TC = Geo<H>::TC;
+    constexpr bool NEEDS_COV = (OP != OP_RFFT2 && OP != OP_INV_RFFT2);
     const int c = threadIdx.x % TC, t = threadIdx.x / TC;
-    // adjacent columns' regions are skewed by 8 elements (128 B): the lanes of one LDS lane group alternate
-    // between columns, and an unskewed region start would put them on the same banks (2-way conflict)
+    // adjacent columns' regions are skewed by 8 elements (64 B): the lanes of one LDS lane group alternate
+    // between columns, and an unskewed region start would put them on the same banks
     double* lds = reinterpret_cast<double*>(smem) + (size_t)c * (H + COL_SKEW);
     cplx* lds0 = reinterpret_cast<cplx*>(smem);    // whole buffer as one complex column (packed column 0)
     double* red = reinterpret_cast<double*>(smem); // reused after the FFTs are done with LDS
     const int64_t b = blockIdx.y;
-    // XCD-aware mapping. Workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 labels the XCD),
-    // and 16 / TC neighbouring column groups read pieces of the SAME 128-byte lines of the spectrum, of
-    // cov and of d/dcov. Give each XCD a contiguous range of column groups, in dispatch order, so that the
-    // sharers meet in one L2 instead of each XCD fetching every line again (speed only, never correctness).
-    int grp = blockIdx.x;
-    {
-        const int ng = gridDim.x;
-        if ((ng & 7) == 0) grp = (blockIdx.x & 7) * (ng >> 3) + (blockIdx.x >> 3);
-    }
-    const int j0 = grp * TC;
-    const int jp = j0 + c; // packed column
     const ZLayout L = make_layout(a);
     const EwPtrs P = make_ptrs(a, b);
     cplx* wsb = ws + (int64_t)b * H * wstride; // uniform base; 32-bit element offsets below
-    cplx v[E];
-    if (op_has_fwd(OP)) {
-#pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = wsb[(unsigned)(t + T * m) * (unsigned)wstride + (unsigned)jp];
-        fft_regs<H, false>(v, t, lds, a.ph.tw);
-    } else {
-#pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = make_double2(0.0, 0.0);
+    cplx wpre[tw_npre<H>()];
+    tw_load<H>(wpre, a.ph.tw, t);
+
+    int first, step, count;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        if ((nwg & 7) == 0 && (ntiles & 7) == 0) {
+            const int per = ntiles >> 3, i = bid >> 3;
+            step = nwg >> 3;
+            first = (bid & 7) * per + i;
+            count = i < per ? (per - i + step - 1) / step : 0;
+        } else {
+            step = nwg;
+            first = bid;
+            count = bid < ntiles ? (ntiles - bid + step - 1) / step : 0;
+        }
     }
     EwAcc acc;
     acc_init(acc);
-    constexpr bool NEEDS_COV = (OP != OP_RFFT2 && OP != OP_INV_RFFT2);
-    const bool own0 = (j0 == 0); // workgroup-uniform: this workgroup owns the packed column 0
-    if (own0) {
-        // Packed column 0 (DC + i*Nyquist): rows k and H-k must meet, so the column goes through LDS and
-        // is processed by a ROLLED loop (few registers, little code; one column out of W/2).
-        __syncthreads();
-        if (c == 0) {
+    cplx nv[E];
+    // `tq` is the thread's row index laundered through an empty asm: every address below then depends on
+    // a per-iteration opaque value, which keeps loop-invariant code motion from hoisting ~100 address
+    // registers out of the tile loop (they are cheap to recompute and expensive to keep).
+    auto prefetch = [&](int tile, int tq) {
+        const unsigned jq = (unsigned)(tile * TC + c);
+        if (op_has_fwd(OP)) {
 #pragma unroll
-            for (int m = 0; m < E; ++m) lds0[phys(t + T * m)] = v[m];
+            for (int m = 0; m < E; ++m) nv[m] = wsb[(unsigned)(tq + T * m) * (unsigned)wstride + jq];
         }
-        __syncthreads();
+    };
+    if (count > 0) prefetch(first, t);
 #pragma unroll 1
-        for (int k = threadIdx.x; k <= H / 2; k += Geo<H>::COL_THREADS) {
-            const bool self = (k == 0) || (k == H / 2);
-            cplx Zk = lds0[phys(k)];
-            cplx Zm = self ? Zk : lds0[phys(H - k)];
-            ew_packed0<OP>(a, L, P, k, Zk, Zm, acc);
-            if (op_has_inv(OP)) {
-                lds0[phys(k)] = Zk;
-                if (!self) lds0[phys(H - k)] = Zm;
+    for (int r = 0; r < count; ++r) {
+        const int tile = first + r * step;
+        const int j0 = tile * TC;
+        const int jp = j0 + c; // packed column
+        int tl = t;
+        asm volatile("" : "+v"(tl));
+        // ... and the twiddle bases: their power trees (60 complex values per tile) would otherwise be
+        // hoisted out of the loop and parked in scratch memory.
+        cplx wl[tw_npre<H>()];
+#pragma unroll
+        for (int i = 0; i < tw_npre<H>(); ++i) {
+            wl[i] = wpre[i];
+            asm volatile("" : "+v"(wl[i].x), "+v"(wl[i].y));
+        }
+        cplx v[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m] = op_has_fwd(OP) ? nv[m] : make_double2(0.0, 0.0);
+        if (r + 1 < count) prefetch(tile + step, tl);
+        if (op_has_fwd(OP)) fft_regs<H, false>(v, tl, lds, wl);
+        const bool own0 = (j0 == 0); // workgroup-uniform: this tile holds the packed column 0
+        if (own0) {
+            // Packed column 0 (DC + i*Nyquist): rows k and H-k must meet, so the column goes through LDS
+            // and is processed by a ROLLED loop (few registers, little code; one column out of W/2).
+            __syncthreads();
+            if (c == 0) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) lds0[phys(tl + T * m)] = v[m];
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int k = threadIdx.x; k <= H / 2; k += Geo<H>::COL_THREADS) {
+                const bool self = (k == 0) || (k == H / 2);
+                cplx Zk = lds0[phys(k)];
+                cplx Zm = self ? Zk : lds0[phys(H - k)];
+                ew_packed0<OP>(a, L, P, k, Zk, Zm, acc);
+                if (op_has_inv(OP)) {
+                    lds0[phys(k)] = Zk;
+                    if (!self) lds0[phys(H - k)] = Zm;
+                }
+            }
+            __syncthreads();
+            if (c == 0 && op_has_inv(OP)) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) v[m] = lds0[phys(tl + T * m)];
+            }
+            __syncthreads();
+        }
+        if (!(own0 && c == 0) && !(GPT_ABLATE & 4)) {
+            // all 16 cov values of this thread are requested before any is used
+            double cv[E];
+#pragma unroll
+            for (int m = 0; m < E; ++m)
+                cv[m] = NEEDS_COV ? P.cov[(unsigned)(tl + T * m) * (unsigned)L.Wf + (unsigned)jp] : 1.0;
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                v[m] = ew_interior_c<OP>(a, L, P, tl + T * m, jp, v[m], cv[m], acc);
+                if ((m & 3) == 3) SCHED_FENCE();
             }
         }
-        __syncthreads();
-        if (c == 0 && op_has_inv(OP)) {
+        acc_fold(acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (op_has_inv(OP)) {
+            // Launder the thread index all LDS addresses derive from, tied to a value the elementwise stage
+            // produced: otherwise the compiler keeps the forward transform's addresses alive to reuse them
+            // here, or schedules parts of the inverse transform above the elementwise stage (spills).
+            int t_inv = tl;
+            asm volatile("" : "+v"(t_inv), "+v"(v[0].x));
 #pragma unroll
-            for (int m = 0; m < E; ++m) v[m] = lds0[phys(t + T * m)];
+            for (int i = 0; i < tw_npre<H>(); ++i) asm volatile("" : "+v"(wl[i].x), "+v"(wl[i].y), "+v"(v[0].x));
+            fft_regs<H, true>(v, t_inv, lds, wl);
+#pragma unroll
+            for (int m = 0; m < E; ++m) wsb[(unsigned)(t_inv + T * m) * (unsigned)wstride + (unsigned)jp] = v[m];
         }
-        __syncthreads();
-    }
-    if (!(own0 && c == 0) && !(GPT_ABLATE & 4)) {
-        // interior columns: all 16 cov values of this thread are requested before any is used
-        double cv[E];
-        if (NEEDS_COV) {
-#pragma unroll
-            for (int m = 0; m < E; ++m) cv[m] = P.cov[(unsigned)(t + T * m) * (unsigned)L.Wf + (unsigned)jp];
-        }
-#pragma unroll
-        for (int m = 0; m < E; ++m)
-            v[m] = ew_interior_c<OP>(a, L, P, t + T * m, jp, v[m], NEEDS_COV ? cv[m] : 1.0, acc);
-    }
-    acc_fold(acc);
-    __builtin_amdgcn_sched_barrier(0);
-    if (op_has_inv(OP)) {
-        // Launder the table pointer: otherwise the compiler keeps all 30 twiddles of the forward transform
-        // alive across the elementwise stage to reuse them here (120 VGPRs -> spills).
-        // The same goes for the thread index all LDS addresses derive from.
-        const cplx* tw_inv = a.ph.tw;
-        int t_inv = t;
-        asm volatile("" : "+s"(tw_inv));
-        // ... tied to a value the elementwise stage produced, so that nothing of the inverse transform
-        // (addresses, twiddle power chains) is scheduled above it.
-        asm volatile("" : "+v"(t_inv), "+v"(v[0].x));
-        fft_regs<H, true>(v, t_inv, lds, tw_inv);
-#pragma unroll
-        for (int m = 0; m < E; ++m) wsb[(unsigned)(t_inv + T * m) * (unsigned)wstride + (unsigned)jp] = v[m];
     }
     if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
         double s = acc.sum, mn = acc.mn;
         block_sum_min(s, mn, red);
         if (threadIdx.x == 0) {
-            double* p = partials + ((int64_t)b * gridDim.x + grp) * GPT_PART;
+            double* p = partials + ((int64_t)b * gridDim.x + blockIdx.x) * GPT_PART;
             p[0] = s;
             p[1] = p[2] = p[3] = p[4] = 0.0;
             p[5] = mn;
@@ -468,7 +548,12 @@ template <int N> struct Launch {
     static hipError_t row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
                               hipStream_t st);
     static hipError_t col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, hipStream_t st);
-    static int col_blocks(int W) { return (W / 2) / Geo<N>::TC; }
+    // grid of the persistent column kernel = number of per-lattice partials
+    static int col_blocks(int W) {
+        const int ntiles = (W / 2) / Geo<N>::TC;
+        const int cap = 256 * GPT_COL_WGS_PER_CU;
+        return ntiles < cap ? ntiles : cap;
+    }
 };
 
 } // namespace pow2

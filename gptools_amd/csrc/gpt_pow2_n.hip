@@ -51,8 +51,10 @@ static hipError_t col_t(const LatArgs& a, cplx* ws, int wstride, double* partial
     const size_t lds = col_lds_bytes<H>();
     hipError_t e = raise_lds(col_kernel<H, OP>, lds);
     if (e != hipSuccess) return e;
-    dim3 grid((a.W / 2) / Geo<H>::TC, (unsigned)a.batch);
-    hipLaunchKernelGGL((col_kernel<H, OP>), grid, dim3(Geo<H>::COL_THREADS), lds, st, a, ws, wstride, partials);
+    const int ntiles = (a.W / 2) / Geo<H>::TC;
+    dim3 grid(Launch<H>::col_blocks(a.W), (unsigned)a.batch);
+    hipLaunchKernelGGL((col_kernel<H, OP>), grid, dim3(Geo<H>::COL_THREADS), lds, st, a, ws, wstride, partials,
+                       ntiles);
     return hipGetLastError();
 }
 
