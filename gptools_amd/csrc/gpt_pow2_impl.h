@@ -29,7 +29,17 @@ constexpr int COL_SKEW = 8;
 
 // Scheduling fence: hipcc's scheduler otherwise interleaves the whole (fully unrolled) transform for ILP and
 // stretches live ranges until the 16-element register tile spills; program order is in-place.
+#ifndef GPT_FENCE
+#define GPT_FENCE 1
+#endif
+#if GPT_FENCE
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SCHED_FENCE() ((void)0)
+#endif
+#ifndef GPT_COV_AHEAD
+#define GPT_COV_AHEAD 0
+#endif
 
 // Timing-only ablation builds (make ABLATE=<bits>): 1 = no butterflies, 2 = no LDS exchanges,
 // 4 = no elementwise stage. Results are wrong by construction; never shipped.
@@ -445,6 +455,7 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
     EwAcc acc;
     acc_init(acc);
     cplx nv[E];
+    double ncv[E];
     // `tq` is the thread's row index laundered through an empty asm: every address below then depends on
     // a per-iteration opaque value, which keeps loop-invariant code motion from hoisting ~100 address
     // registers out of the tile loop (they are cheap to recompute and expensive to keep).
@@ -453,6 +464,10 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
         if (op_has_fwd(OP)) {
 #pragma unroll
             for (int m = 0; m < E; ++m) nv[m] = wsb[(unsigned)(tq + T * m) * (unsigned)wstride + jq];
+        }
+        if (NEEDS_COV && GPT_COV_AHEAD) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) ncv[m] = P.cov[(unsigned)(tq + T * m) * (unsigned)L.Wf + jq];
         }
     };
     if (count > 0) prefetch(first, t);
@@ -472,8 +487,12 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
             asm volatile("" : "+v"(wl[i].x), "+v"(wl[i].y));
         }
         cplx v[E];
+        double cv[E];
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = op_has_fwd(OP) ? nv[m] : make_double2(0.0, 0.0);
+        for (int m = 0; m < E; ++m) {
+            v[m] = op_has_fwd(OP) ? nv[m] : make_double2(0.0, 0.0);
+            cv[m] = (NEEDS_COV && GPT_COV_AHEAD) ? ncv[m] : 1.0;
+        }
         if (r + 1 < count) prefetch(tile + step, tl);
         if (op_has_fwd(OP)) fft_regs<H, false>(v, tl, lds, wl);
         const bool own0 = (j0 == 0); // workgroup-uniform: this tile holds the packed column 0
@@ -505,11 +524,10 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
             __syncthreads();
         }
         if (!(own0 && c == 0) && !(GPT_ABLATE & 4)) {
-            // all 16 cov values of this thread are requested before any is used
-            double cv[E];
+            if (NEEDS_COV && !GPT_COV_AHEAD) {
 #pragma unroll
-            for (int m = 0; m < E; ++m)
-                cv[m] = NEEDS_COV ? P.cov[(unsigned)(tl + T * m) * (unsigned)L.Wf + (unsigned)jp] : 1.0;
+                for (int m = 0; m < E; ++m) cv[m] = P.cov[(unsigned)(tl + T * m) * (unsigned)L.Wf + (unsigned)jp];
+            }
 #pragma unroll
             for (int m = 0; m < E; ++m) {
                 v[m] = ew_interior_c<OP>(a, L, P, tl + T * m, jp, v[m], cv[m], acc);
