@@ -46,6 +46,12 @@ _SIGNATURES = {
     "gpt_gp_rfft2_lpdf_host": [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr],
     "gpt_gp_inv_rfft2_vjp_host": [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr],
     "gpt_gp_rfft2_vjp_host": [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr],
+    "gpt_rfft2_host": [c_int, c_ptr, c_i64, c_i64, c_ptr],
+    "gpt_inv_rfft2_host": [c_int, c_ptr, c_i64, c_i64, c_ptr],
+    "gpt_expand_rfft_host": [c_ptr, c_i64, c_ptr],
+    "gpt_gp_evaluate_rfft2_scale_host": [c_int, c_ptr, c_i64, c_i64, c_int, c_ptr],
+    "gpt_gp_unpack_rfft2_host": [c_int, c_ptr, c_i64, c_i64, c_int, c_ptr],
+    "gpt_gp_pack_rfft2_host": [c_int, c_ptr, c_i64, c_i64, c_int, c_ptr],
     "gpt_gp_periodic_exp_quad_cov_rfft2_host": [c_int, c_i64, c_i64, c_ptr, c_int, c_ptr],
     "gpt_gp_periodic_matern_cov_rfft2_host": [c_int, c_dbl, c_i64, c_i64, c_ptr, c_int, c_ptr],
     "gpt_gp_periodic_exp_quad_cov_rfft2_vjp_host": [c_int, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr],

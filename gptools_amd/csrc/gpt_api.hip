@@ -758,6 +758,88 @@ int gpt_gp_rfft2_vjp_host(gpt_ctx* c, int layout, const double* y, const double*
     return s.finish(nullptr);
 }
 
+// ---- host-pointer versions of the real-FFT layer and of the layout helpers (double only) ---------------
+int gpt_rfft2_host(gpt_ctx* c, int layout, const double* y, int64_t H, int64_t W, double* out_complex) {
+    int rc = check_shape(c, H, W, 1, 0);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 6));
+    const double* dy = (const double*)s.up(y, H, W, 8);
+    double* dout = (double*)s.dev(H, Wf, 16);
+    if (s.rc) return s.rc;
+    if ((rc = gpt_rfft2(c, dy, H, W, 1, dout))) return rc;
+    s.down(out_complex, dout, H, Wf, 16);
+    return s.finish(nullptr);
+}
+
+int gpt_inv_rfft2_host(gpt_ctx* c, int layout, const double* z_complex, int64_t H, int64_t W, double* out) {
+    int rc = check_shape(c, H, W, 1, 0);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 8));
+    const double* dz = (const double*)s.up(z_complex, H, Wf, 16);
+    double* dout = (double*)s.dev(H, W, 8);
+    if (s.rc) return s.rc;
+    if ((rc = gpt_inv_rfft2(c, dz, H, W, 1, dout))) return rc;
+    s.down(out, dout, H, W, 8);
+    return s.finish(nullptr);
+}
+
+int gpt_expand_rfft_host(gpt_ctx* c, const double* y_complex, int64_t n, double* out_complex) {
+    int rc = check_shape(c, 1, n, 1, 1);
+    if (rc) return rc;
+    Stager s(c, GPT_ROW_MAJOR, arena_need(1, n, 8));
+    const double* dy = (const double*)s.up(y_complex, 1, n / 2 + 1, 16);
+    double* dout = (double*)s.dev(1, n, 16);
+    if (s.rc) return s.rc;
+    if ((rc = gpt_expand_rfft(c, dy, n, 1, dout))) return rc;
+    s.down(out_complex, dout, 1, n, 16);
+    return s.finish(nullptr);
+}
+
+int gpt_gp_evaluate_rfft2_scale_host(gpt_ctx* c, int layout, const double* cov, int64_t H, int64_t W, int dim1,
+                                     double* out) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 4));
+    const double* dc = (const double*)s.up(cov, H, Wf, 8);
+    double* dout = (double*)s.dev(H, Wf, 8);
+    double* dm = (double*)s.dev(1, 1, 8);
+    if (s.rc) return s.rc;
+    if ((rc = gpt_gp_evaluate_rfft2_scale(c, dc, 0, H, W, 1, dim1, dout, dm))) return rc;
+    s.down(out, dout, H, Wf, 8);
+    return s.finish(dm);
+}
+
+int gpt_gp_unpack_rfft2_host(gpt_ctx* c, int layout, const double* z_complex, int64_t H, int64_t W, int dim1,
+                             double* out) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 8));
+    const double* dz = (const double*)s.up(z_complex, H, Wf, 16);
+    double* dout = (double*)s.dev(H, W, 8);
+    if (s.rc) return s.rc;
+    if ((rc = gpt_gp_unpack_rfft2(c, dz, H, W, 1, dim1, dout))) return rc;
+    s.down(out, dout, H, W, 8);
+    return s.finish(nullptr);
+}
+
+int gpt_gp_pack_rfft2_host(gpt_ctx* c, int layout, const double* z, int64_t H, int64_t W, int dim1,
+                           double* out_complex) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 8));
+    const double* dz = (const double*)s.up(z, H, W, 8);
+    double* dout = (double*)s.dev(H, Wf, 16);
+    if (s.rc) return s.rc;
+    if ((rc = gpt_gp_pack_rfft2(c, dz, H, W, 1, dim1, dout))) return rc;
+    s.down(out_complex, dout, H, Wf, 16);
+    return s.finish(nullptr);
+}
+
 static int spec_host(gpt_ctx* c, int layout, bool matern, double nu, int64_t H, int64_t W, const double* params,
                      int dim1, double* out) {
     int rc = check_shape(c, H, W, 1, dim1);

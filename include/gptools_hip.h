@@ -160,6 +160,18 @@ int gpt_gp_inv_rfft2_vjp_host(gpt_ctx*, int layout, const double* z, const doubl
 int gpt_gp_rfft2_vjp_host(gpt_ctx*, int layout, const double* y, const double* loc, const double* cov,
                           const double* zbar, int64_t height, int64_t width, int dim1, double* ybar,
                           double* covbar);
+/* Real-FFT layer and layout helpers on host pointers (values only; the reference uses them in tests and
+ * generated quantities): rfft/rfft2 (util.stan:263,302), inv_rfft/inv_rfft2 (util.stan:291,315),
+ * expand_rfft (util.stan:271), gp_evaluate_rfft(2)_scale, gp_unpack_rfft(2), gp_pack_rfft(2). */
+int gpt_rfft2_host(gpt_ctx*, int layout, const double* y, int64_t height, int64_t width, double* out_complex);
+int gpt_inv_rfft2_host(gpt_ctx*, int layout, const double* z_complex, int64_t height, int64_t width, double* out);
+int gpt_expand_rfft_host(gpt_ctx*, const double* y_complex, int64_t n, double* out_complex);
+int gpt_gp_evaluate_rfft2_scale_host(gpt_ctx*, int layout, const double* cov, int64_t height, int64_t width,
+                                     int dim1, double* out);
+int gpt_gp_unpack_rfft2_host(gpt_ctx*, int layout, const double* z_complex, int64_t height, int64_t width,
+                             int dim1, double* out);
+int gpt_gp_pack_rfft2_host(gpt_ctx*, int layout, const double* z, int64_t height, int64_t width, int dim1,
+                           double* out_complex);
 int gpt_gp_periodic_exp_quad_cov_rfft2_host(gpt_ctx*, int layout, int64_t height, int64_t width,
                                             const double* params, int dim1, double* out);
 int gpt_gp_periodic_matern_cov_rfft2_host(gpt_ctx*, int layout, double nu, int64_t height, int64_t width,

@@ -242,6 +242,28 @@ def test_host_entry_points_col_major(fft):
         rc = lib.gpt_gp_inv_rfft2_host(ctx.handle, _lib.GPT_COL_MAJOR, P(yF), P(locF), P(covF), h, w, dim1, P(f))
         assert rc == 0, ctx.error()
         close(f, o.gp_inv_rfft(y[0], loc[0], cov[0])[None] if dim1 else o.gp_inv_rfft2(y, loc, cov))
+        # real-FFT layer and layout helpers on host pointers
+        if not dim1:
+            zc = np.zeros((h, wf), dtype=complex, order="F")
+            assert lib.gpt_rfft2_host(ctx.handle, _lib.GPT_COL_MAJOR, P(yF), h, w, P(zc)) == 0, ctx.error()
+            close(zc, o.rfft2(y))
+            back = np.zeros((h, w), order="F")
+            assert lib.gpt_inv_rfft2_host(ctx.handle, _lib.GPT_COL_MAJOR, P(zc), h, w, P(back)) == 0, ctx.error()
+            close(back, y)
+            un = np.zeros((h, w), order="F")
+            assert lib.gpt_gp_unpack_rfft2_host(ctx.handle, _lib.GPT_COL_MAJOR, P(zc), h, w, 0, P(un)) == 0
+            assert np.array_equal(un, o.gp_unpack_rfft2(np.ascontiguousarray(zc), w))
+            pk = np.zeros((h, wf), dtype=complex, order="F")
+            assert lib.gpt_gp_pack_rfft2_host(ctx.handle, _lib.GPT_COL_MAJOR, P(un), h, w, 0, P(pk)) == 0
+            assert np.array_equal(pk, o.gp_pack_rfft2(un))
+            sc = np.zeros((h, wf), order="F")
+            assert lib.gpt_gp_evaluate_rfft2_scale_host(ctx.handle, _lib.GPT_COL_MAJOR, P(covF), h, w, 0, P(sc)) == 0
+            close(sc, o.gp_evaluate_rfft2_scale(cov, w))
+        else:
+            ex = np.zeros(w, dtype=complex)
+            half = np.ascontiguousarray(o.rfft(y[0]))
+            assert lib.gpt_expand_rfft_host(ctx.handle, P(half), w, P(ex)) == 0, ctx.error()
+            close(ex, np.fft.fft(y[0]))
         # reject -> status 1 and the reference's message
         covF[0, 0] = -1.0
         rc = lib.gpt_gp_rfft2_lpdf_host(ctx.handle, _lib.GPT_COL_MAJOR, P(yF), P(locF), P(covF), h, w, dim1, P(lp),
