@@ -1,6 +1,293 @@
+// Generic three-pass path: lattices of ANY shape (mixed radix, arbitrary prime factors) that are too large
+// for one workgroup's LDS (gpt_small.hip) and are not power-of-two sized (gpt_pow2_impl.h). Same structure
+// and the same packed-spectrum workspace as the power-of-two path, with the transforms done by the LDS
+// Stockham routine of gpt_lds_fft.h (ping-pong buffers), so one line of up to 4096 points fits a workgroup:
+//   pass A  g_row_fwd  LP row pairs per workgroup: two-for-one real transform, split, pack
+//   pass B  g_col      TC adjacent packed columns per workgroup: column FFT, elementwise stage, inverse FFT
+//   pass C  g_row_inv  LP row pairs per workgroup: merge, inverse transform, store
+// Correctness-first: the tuned code is the power-of-two path.
 #include "gpt_common.h"
 #include "gpt_host.h"
-bool gpt_generic_supported(int, int) { return false; }
-size_t gpt_generic_workspace_bytes(int, int) { return 0; }
-int gpt_generic_col_blocks(int, int) { return 1; }
-hipError_t gpt_launch_generic(int, const LatArgs&, cplx*, double*, hipStream_t) { return hipErrorNotSupported; }
+#include "gpt_lds_fft.h"
+
+namespace {
+
+constexpr int G_THREADS = 512;
+constexpr int G_MAX_LINE = 4096;      // longest transform (complex points) held in LDS, twice
+constexpr int G_BUF_ELEMS = 4096;     // elements per ping-pong buffer (64 KB)
+
+struct GenGeo {
+    int NC;      // packed columns
+    int wstride; // workspace row stride (complex elements)
+    int Hp;      // row pairs
+    int LP;      // row pairs per workgroup
+    int TC;      // columns per workgroup
+    int TCs;     // LDS stride between rows of a column tile (odd)
+};
+
+GenGeo make_geo(int H, int W) {
+    GenGeo g;
+    g.NC = 1 + (W - 1) / 2;
+    g.wstride = (g.NC + 7) / 8 * 8 + 8;
+    g.Hp = (H + 1) / 2;
+    g.LP = G_BUF_ELEMS / W;
+    if (g.LP < 1) g.LP = 1;
+    if (g.LP > g.Hp) g.LP = g.Hp;
+    g.TC = G_BUF_ELEMS / H;
+    if (g.TC > 16) g.TC = 16;
+    if (g.TC < 1) g.TC = 1;
+    if (g.TC > g.NC) g.TC = g.NC;
+    g.TCs = g.TC | 1;
+    while ((int64_t)H * g.TCs > G_BUF_ELEMS && g.TC > 1) { // keep H * TCs within the buffer
+        g.TC -= 1;
+        g.TCs = g.TC | 1;
+    }
+    return g;
+}
+
+template <int IN_MODE> // 0 = x, 1 = x - loc, 2 = aux
+__device__ __forceinline__ double g_in(const LatArgs& a, int64_t b, int i, int j) {
+    const int64_t off = (int64_t)i * a.W + j;
+    if (IN_MODE == 2) return a.aux[b * a.aux_bs + off];
+    const double v = a.x[b * a.x_bs + off];
+    if (IN_MODE == 1 && a.loc) return v - a.loc[b * a.loc_bs + off];
+    return v;
+}
+
+template <int IN_MODE>
+__global__ void __launch_bounds__(G_THREADS) g_row_fwd(LatArgs a, GenGeo g, cplx* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cplx* cur = reinterpret_cast<cplx*>(smem);
+    cplx* oth = cur + G_BUF_ELEMS;
+    const int64_t b = blockIdx.y;
+    const int H = a.H, W = a.W;
+    const int r0 = blockIdx.x * g.LP;
+    const int nl = min(g.LP, g.Hp - r0);
+    const bool weven = (W % 2) == 0;
+    for (int w = threadIdx.x; w < nl * W; w += blockDim.x) {
+        const int l = w / W, j = w - l * W, r = r0 + l;
+        const double re = g_in<IN_MODE>(a, b, 2 * r, j);
+        const double im = (2 * r + 1 < H) ? g_in<IN_MODE>(a, b, 2 * r + 1, j) : 0.0;
+        cur[w] = make_double2(re, im);
+    }
+    __syncthreads();
+    const cplx* res = fft_lines_lds<false>(cur, oth, a.pw, nl, 1, W);
+    cplx* wsb = ws + (int64_t)b * H * g.wstride;
+    for (int w = threadIdx.x; w < 2 * nl * g.NC; w += blockDim.x) {
+        const int li = w / g.NC, jp = w - li * g.NC;
+        const int l = li >> 1, odd = li & 1;
+        const int i = 2 * (r0 + l) + odd;
+        if (i >= H) continue;
+        const cplx* line = res + l * W;
+        auto rowspec = [&](int j) -> cplx {
+            const cplx z = line[j];
+            const cplx zc = line[j == 0 ? 0 : W - j];
+            if (!odd) return make_double2(0.5 * (z.x + zc.x), 0.5 * (z.y - zc.y));
+            return make_double2(0.5 * (z.y + zc.y), -0.5 * (z.x - zc.x));
+        };
+        cplx v;
+        if (jp == 0) {
+            v.x = rowspec(0).x;
+            v.y = weven ? rowspec(W / 2).x : 0.0;
+        } else {
+            v = rowspec(jp);
+        }
+        wsb[(int64_t)i * g.wstride + jp] = v;
+    }
+}
+
+template <int OP>
+__global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, cplx* __restrict__ ws,
+                                                    double* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* red = reinterpret_cast<double*>(smem); // 512 bytes
+    cplx* cur = reinterpret_cast<cplx*>(smem + 512);
+    cplx* oth = cur + G_BUF_ELEMS + 16;
+    const int64_t b = blockIdx.y;
+    const int H = a.H;
+    const ZLayout L = make_layout(a);
+    const EwPtrs P = make_ptrs(a, b);
+    const int j0 = blockIdx.x * g.TC;
+    const int nc = min(g.TC, g.NC - j0);
+    const int sS = g.TCs;
+    cplx* wsb = ws + (int64_t)b * H * g.wstride;
+    if (op_has_fwd(OP)) {
+        for (int w = threadIdx.x; w < H * nc; w += blockDim.x) {
+            const int k = w / nc, c = w - k * nc;
+            cur[k * sS + c] = wsb[(int64_t)k * g.wstride + j0 + c];
+        }
+        __syncthreads();
+        cplx* res = fft_lines_lds<false>(cur, oth, a.ph, nc, sS, 1);
+        if (res != cur) {
+            oth = cur;
+            cur = res;
+        }
+    }
+    EwAcc acc;
+    acc_init(acc);
+    for (int w = threadIdx.x; w < H * nc; w += blockDim.x) {
+        const int k = w / nc, c = w - k * nc;
+        const int jp = j0 + c;
+        if (jp == 0) continue;
+        const cplx G = ew_interior<OP>(a, L, P, k, jp, cur[k * sS + c], acc);
+        if (op_has_inv(OP)) cur[k * sS + c] = G;
+        acc_renorm(acc);
+    }
+    if (j0 == 0) {
+        for (int k = threadIdx.x; k <= H / 2; k += blockDim.x) {
+            const int km = (H - k) % H;
+            cplx Zk = cur[k * sS], Zm = cur[km * sS];
+            ew_packed0<OP>(a, L, P, k, Zk, Zm, acc);
+            if (op_has_inv(OP)) {
+                cur[k * sS] = Zk;
+                if (km != k) cur[km * sS] = Zm;
+            }
+        }
+    }
+    acc_fold(acc);
+    __syncthreads();
+    if (op_has_inv(OP)) {
+        const cplx* res = fft_lines_lds<true>(cur, oth, a.ph, nc, sS, 1);
+        for (int w = threadIdx.x; w < H * nc; w += blockDim.x) {
+            const int k = w / nc, c = w - k * nc;
+            wsb[(int64_t)k * g.wstride + j0 + c] = res[k * sS + c];
+        }
+    }
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
+        double s = acc.sum, mn = acc.mn;
+        block_sum_min(s, mn, red);
+        if (threadIdx.x == 0) {
+            double* p = partials + ((int64_t)b * gridDim.x + blockIdx.x) * GPT_PART;
+            p[0] = s;
+            p[1] = p[2] = p[3] = p[4] = 0.0;
+            p[5] = mn;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, double alpha, int add_loc,
+                                                       const cplx* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cplx* cur = reinterpret_cast<cplx*>(smem);
+    cplx* oth = cur + G_BUF_ELEMS;
+    const int64_t b = blockIdx.y;
+    const int H = a.H, W = a.W;
+    const int r0 = blockIdx.x * g.LP;
+    const int nl = min(g.LP, g.Hp - r0);
+    const bool weven = (W % 2) == 0;
+    const cplx* wsb = ws + (int64_t)b * H * g.wstride;
+    for (int w = threadIdx.x; w < nl * W; w += blockDim.x) {
+        const int l = w / W, j = w - l * W, r = r0 + l;
+        auto rowspec = [&](int i, int jj) -> cplx {
+            const bool mir = jj > W / 2;
+            const int q = mir ? W - jj : jj;
+            const cplx* row = wsb + (int64_t)i * g.wstride;
+            cplx v;
+            if (q == 0) v = make_double2(row[0].x, 0.0);
+            else if (weven && q == W / 2) v = make_double2(row[0].y, 0.0);
+            else v = row[q];
+            if (mir) v.y = -v.y;
+            return v;
+        };
+        const cplx A = rowspec(2 * r, j);
+        cplx B = make_double2(0.0, 0.0);
+        if (2 * r + 1 < H) B = rowspec(2 * r + 1, j);
+        cur[w] = make_double2(A.x - B.y, A.y + B.x);
+    }
+    __syncthreads();
+    const cplx* res = fft_lines_lds<true>(cur, oth, a.pw, nl, 1, W);
+    double* ob = a.out + b * (int64_t)H * W;
+    for (int w = threadIdx.x; w < nl * W; w += blockDim.x) {
+        const int l = w / W, j = w - l * W, r = r0 + l;
+        const cplx v = res[w];
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * r + h;
+            if (i >= H) break;
+            double o = alpha * (h ? v.y : v.x);
+            if (add_loc && a.loc) o += a.loc[b * a.loc_bs + (int64_t)i * W + j];
+            ob[(int64_t)i * W + j] = o;
+        }
+    }
+}
+
+template <int OP>
+hipError_t launch_col(const LatArgs& a, const GenGeo& g, cplx* ws, double* partials, int nblk, hipStream_t st) {
+    const size_t lds = 512 + 2 * (size_t)(G_BUF_ELEMS + 16) * sizeof(cplx);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g_col<OP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(g_col<OP>, dim3(nblk, (unsigned)a.batch), dim3(G_THREADS), lds, st, a, g, ws, partials);
+    return hipGetLastError();
+}
+
+template <int IN_MODE> hipError_t launch_row_fwd(const LatArgs& a, const GenGeo& g, cplx* ws, hipStream_t st) {
+    const size_t lds = 2 * (size_t)G_BUF_ELEMS * sizeof(cplx);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g_row_fwd<IN_MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int nb = (g.Hp + g.LP - 1) / g.LP;
+    hipLaunchKernelGGL(g_row_fwd<IN_MODE>, dim3(nb, (unsigned)a.batch), dim3(G_THREADS), lds, st, a, g, ws);
+    return hipGetLastError();
+}
+
+} // namespace
+
+bool gpt_generic_supported(int H, int W) { return H >= 1 && W >= 2 && H <= G_MAX_LINE && W <= G_MAX_LINE; }
+
+size_t gpt_generic_workspace_bytes(int H, int W) {
+    const GenGeo g = make_geo(H, W);
+    return (size_t)H * (size_t)g.wstride * sizeof(cplx);
+}
+
+int gpt_generic_col_blocks(int H, int W) {
+    const GenGeo g = make_geo(H, W);
+    return (g.NC + g.TC - 1) / g.TC;
+}
+
+hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partials, hipStream_t st) {
+    if (!gpt_generic_supported(a.H, a.W)) return hipErrorInvalidValue;
+    const GenGeo g = make_geo(a.H, a.W);
+    const int nblk = gpt_generic_col_blocks(a.H, a.W);
+    const double n = (double)a.H * (double)a.W;
+    hipError_t e = hipSuccess;
+    if (op_has_fwd(op)) {
+        if (op == OP_RFFT2) e = launch_row_fwd<0>(a, g, ws, st);
+        else if (op == OP_INV_VJP) e = launch_row_fwd<2>(a, g, ws, st);
+        else e = launch_row_fwd<1>(a, g, ws, st);
+        if (e != hipSuccess) return e;
+    }
+    switch (op) {
+    case OP_RFFT2: e = launch_col<OP_RFFT2>(a, g, ws, partials, nblk, st); break;
+    case OP_INV_RFFT2: e = launch_col<OP_INV_RFFT2>(a, g, ws, partials, nblk, st); break;
+    case OP_GP_RFFT2: e = launch_col<OP_GP_RFFT2>(a, g, ws, partials, nblk, st); break;
+    case OP_GP_INV_RFFT2: e = launch_col<OP_GP_INV_RFFT2>(a, g, ws, partials, nblk, st); break;
+    case OP_LPDF: e = launch_col<OP_LPDF>(a, g, ws, partials, nblk, st); break;
+    case OP_LPDF_VJP: e = launch_col<OP_LPDF_VJP>(a, g, ws, partials, nblk, st); break;
+    case OP_INV_VJP: e = launch_col<OP_INV_VJP>(a, g, ws, partials, nblk, st); break;
+    case OP_FWD_VJP: e = launch_col<OP_FWD_VJP>(a, g, ws, partials, nblk, st); break;
+    case OP_LPDF_VJP_NOCOV: e = launch_col<OP_LPDF_VJP_NOCOV>(a, g, ws, partials, nblk, st); break;
+    default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+    if (op != OP_RFFT2 && op != OP_INV_RFFT2) {
+        const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op));
+        e = gpt_launch_finalize(partials, nblk, a.batch, 1, -0.5 * n * 1.8378770664093454836,
+                                lp ? a.out_lpdf : nullptr, a.min_eig, st);
+        if (e != hipSuccess) return e;
+    }
+    if (op_has_inv(op)) {
+        double alpha = 1.0;
+        int add_loc = 0;
+        if (op == OP_INV_RFFT2) alpha = 1.0 / n;
+        else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
+        else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
+        const size_t lds = 2 * (size_t)G_BUF_ELEMS * sizeof(cplx);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g_row_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        if (e != hipSuccess) return e;
+        const int nb = (g.Hp + g.LP - 1) / g.LP;
+        hipLaunchKernelGGL(g_row_inv, dim3(nb, (unsigned)a.batch), dim3(G_THREADS), lds, st, a, g, alpha, add_loc, ws);
+        e = hipGetLastError();
+    }
+    return e;
+}
