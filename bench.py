@@ -98,7 +98,7 @@ def main():
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
 
-    from gptools_amd import fft
+    from gptools_amd import fft, sharding
 
     size, B = args.size, args.batch
     h = w = size
@@ -136,10 +136,7 @@ def main():
     if profile:
         ctx.lib.gpt_profile_end(ctx.handle, pass_ms, ctypes.byref(launches))
     barrier()
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, device=device)  # the job's clock is its slowest rank
 
     # sanity of what was computed in the timed region (not timed): finite values, PD check passed
     assert bool(torch.isfinite(lp).all()) and float(mn.min()) >= 0.0, "benchmark produced invalid results"
