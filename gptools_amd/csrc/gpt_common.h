@@ -116,6 +116,33 @@ __device__ __forceinline__ void block_sum_min(double& s, double& m, double* red)
     }
 }
 
+// Second reduction stage folded into a later kernel of the same stream: one workgroup sums the per-workgroup
+// partials of lattice b (slot 0 = log-density terms, slot 5 = min of the scaled spectrum) in a fixed order.
+// Every thread of the workgroup must call it; `red` is LDS scratch of 2 * (blockDim.x / 64) doubles.
+#ifndef GPT_PART
+#define GPT_PART 8 // doubles per workgroup partial (gpt_host.h)
+#endif
+struct FinArgs {
+    const double* partials; // null: nothing to do
+    int nblk;
+    double add;
+    double* out_sum; // may be null
+    double* out_min; // may be null
+};
+__device__ __forceinline__ void finalize_block(const FinArgs& f, int64_t b, double* red) {
+    const double* p = f.partials + b * (int64_t)f.nblk * GPT_PART;
+    double s = 0.0, mn = INFINITY;
+    for (int i = threadIdx.x; i < f.nblk; i += blockDim.x) {
+        s += p[(int64_t)i * GPT_PART];
+        mn = fmin(mn, p[(int64_t)i * GPT_PART + 5]);
+    }
+    block_sum_min(s, mn, red);
+    if (threadIdx.x == 0) {
+        if (f.out_sum) f.out_sum[b] = s + f.add;
+        if (f.out_min) f.out_min[b] = mn;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Packing layout of the whitened coefficients z (the bit-exact contract of the reference).
 // 2-D (fft2.stan:55-74): column 0 <- edge column j=0; columns 1..wc <- Re of j=1..wc; columns
@@ -271,9 +298,10 @@ __device__ __forceinline__ cplx ew_interior(const LatArgs& a, const ZLayout& L, 
 // mirror row H-k is never read by the reference in the forward direction (fft2.stan:65,71), but whose
 // scale IS used, row by row, in the inverse direction (fft2.stan:127-128).
 // Returns the replacement value at row k; the caller mirrors it (conj) to row H-k.
+// `c`, `cm`: cov at (k, j) and at the mirror row (ignored by the ops without cov).
 template <int OP>
-__device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k, int j, cplx FA,
-                                       EwAcc& acc) {
+__device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k, int j, cplx FA,
+                                         double c, double cm, EwAcc& acc) {
     const double n = (double)a.H * (double)a.W;
     const bool real_pt = (k == 0) || (2 * k == a.H);
     const int km = real_pt ? k : a.H - k; // mirror row
@@ -295,8 +323,7 @@ __device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, cons
         const cplx v = P.cin[cm_];
         return make_double2(0.5 * (u.x + v.x), 0.5 * (u.y - v.y));
     }
-    const double c = P.cov[ck];
-    const double cm = real_pt ? c : P.cov[cm_];
+    if (real_pt) cm = c;
     acc.mn = fmin(acc.mn, 0.5 * n * fmin(c, cm));
     const int jz = L.edge_col(j);
     // position of Re/Im of row k inside the packed z column (fft1.stan:44-51 along the height);
@@ -371,23 +398,62 @@ __device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, cons
     return ret;
 }
 
+// Same, loading cov itself.
+template <int OP>
+__device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k, int j, cplx FA,
+                                       EwAcc& acc) {
+    double c = 1.0, cm = 1.0;
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
+        const bool real_pt = (k == 0) || (2 * k == a.H);
+        c = P.cov[(unsigned)k * (unsigned)L.Wf + (unsigned)j];
+        cm = real_pt ? c : P.cov[(unsigned)(a.H - k) * (unsigned)L.Wf + (unsigned)j];
+    }
+    return ew_edge_c<OP>(a, L, P, k, j, FA, c, cm, acc);
+}
+
+// cov values the packed column 0 needs at row k: edge column 0 (c0, c0m = mirror row) and W/2 (ch, chm).
+struct EdgeCov {
+    double c0, c0m, ch, chm;
+};
+template <int OP>
+__device__ __forceinline__ EdgeCov load_edge_cov(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k) {
+    EdgeCov e = {1.0, 1.0, 1.0, 1.0};
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
+        const bool real_pt = (k == 0) || (2 * k == a.H);
+        const unsigned rk = (unsigned)k * (unsigned)L.Wf, rm = (unsigned)(real_pt ? k : a.H - k) * (unsigned)L.Wf;
+        e.c0 = P.cov[rk];
+        e.c0m = P.cov[rm];
+        if ((a.W % 2) == 0) {
+            e.ch = P.cov[rk + (unsigned)(a.W / 2)];
+            e.chm = P.cov[rm + (unsigned)(a.W / 2)];
+        }
+    }
+    return e;
+}
+
 // Elementwise stage on the packed column 0 at row k in 0..H/2: Zk = Z[k], Zm = Z[(H-k)%H] on entry
 // (forward ops) and on exit (inverse ops). Splits into the two edge columns, applies ew_edge, recombines.
 template <int OP>
-__device__ __forceinline__ void ew_packed0(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k, cplx& Zk,
-                                           cplx& Zm, EwAcc& acc) {
+__device__ __forceinline__ void ew_packed0_c(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k, cplx& Zk,
+                                             cplx& Zm, const EdgeCov& ec, EwAcc& acc) {
     const bool weven = (a.W % 2) == 0;
     // A = (Zk + conj Zm)/2 ; B = (Zk - conj Zm)/(2i)
     cplx A = make_double2(0.5 * (Zk.x + Zm.x), 0.5 * (Zk.y - Zm.y));
     cplx B = make_double2(0.5 * (Zk.y + Zm.y), -0.5 * (Zk.x - Zm.x));
-    A = ew_edge<OP>(a, L, P, k, 0, A, acc);
-    if (weven) B = ew_edge<OP>(a, L, P, k, a.W / 2, B, acc);
+    A = ew_edge_c<OP>(a, L, P, k, 0, A, ec.c0, ec.c0m, acc);
+    if (weven) B = ew_edge_c<OP>(a, L, P, k, a.W / 2, B, ec.ch, ec.chm, acc);
     else B = make_double2(0.0, 0.0);
     if (op_has_inv(OP)) {
         // Z[k] = A + iB ; Z[H-k] = conj(A) + i conj(B)
         Zk = make_double2(A.x - B.y, A.y + B.x);
         Zm = make_double2(A.x + B.y, -A.y + B.x);
     }
+}
+
+template <int OP>
+__device__ __forceinline__ void ew_packed0(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k, cplx& Zk,
+                                           cplx& Zm, EwAcc& acc) {
+    ew_packed0_c<OP>(a, L, P, k, Zk, Zm, load_edge_cov<OP>(a, L, P, k), acc);
 }
 
 // Output transform of the final (real) stage.

@@ -54,7 +54,9 @@ hipError_t gpt_launch_elem(int op, const ElemArgs& e, double* partials, hipStrea
 // Second (atomic-free) reduction stage. `partials` is [batch][nblk][GPT_PART] doubles: slots 0..4 are
 // sums, slot 5 a minimum. Emits out_sum[b * K + k] = sum_k (+ add for k == 0) for k < K (if out_sum) and
 // out_min[b] (if out_min).
+#ifndef GPT_PART
 #define GPT_PART 8
+#endif
 hipError_t gpt_launch_finalize(const double* partials, int nblk, int64_t batch, int K, double add,
                                double* out_sum, double* out_min, hipStream_t st);
 // Row-major <-> column-major (Stan/Eigen) transposes of a batch of R x C matrices of `esz`-byte elements.

@@ -48,12 +48,20 @@ hipError_t gpt_launch_pow2(int op, const LatArgs& a, cplx* ws, double* partials,
     e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, ws, wstride, partials, st); });
     if (e != hipSuccess) return e;
     mark(2);
+    // second reduction stage of the column pass: folded into pass C when there is one
+    FinArgs fin = {nullptr, 0, 0.0, nullptr, nullptr};
     if (op != OP_RFFT2 && op != OP_INV_RFFT2) {
-        const int nblk = gpt_pow2_col_blocks(a.H, a.W);
         const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op));
-        e = gpt_launch_finalize(partials, nblk, a.batch, 1, -0.5 * n * 1.8378770664093454836,
-                                lp ? a.out_lpdf : nullptr, a.min_eig, st);
-        if (e != hipSuccess) return e;
+        fin.partials = partials;
+        fin.nblk = gpt_pow2_col_blocks(a.H, a.W);
+        fin.add = -0.5 * n * 1.8378770664093454836;
+        fin.out_sum = lp ? a.out_lpdf : nullptr;
+        fin.out_min = a.min_eig;
+        if (!op_has_inv(op)) {
+            e = gpt_launch_finalize(partials, fin.nblk, a.batch, 1, fin.add, fin.out_sum, fin.out_min, st);
+            if (e != hipSuccess) return e;
+            fin.partials = nullptr;
+        }
     }
     mark(3);
     if (op_has_inv(op)) {
@@ -62,7 +70,7 @@ hipError_t gpt_launch_pow2(int op, const LatArgs& a, cplx* ws, double* partials,
         if (op == OP_INV_RFFT2) alpha = 1.0 / n;
         else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
         else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
-        e = by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, st); });
+        e = by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, fin, st); });
     }
     mark(4);
     return e;

@@ -10,14 +10,36 @@
 //   pass C  row_inv   one workgroup per row pair: merge the two half spectra into one complex line,
 //                     inverse FFT, write the two real rows (scaled, +loc / negated as the op needs).
 //
-// Line FFT: each thread keeps E = 16 complex fp64 elements in registers (v[m] <-> element t + T*m,
-// T = N/16 threads per line). Every Stockham stage is a radix-16 (last stage 2/4/8/16) butterfly on
-// registers followed by an exchange through LDS; LDS is addressed through an XOR swizzle so that both the
-// strided writes and the contiguous reads of an exchange are (nearly) bank-conflict free without padding:
-// a 4096-point line needs exactly 64 KB.
+// Line FFT: a "register tile" is E = 16 complex fp64 elements (v[m] <-> element t + T*m, T = N/16 tiles per
+// line). Every Stockham stage is a radix-16 (last stage 2/4/8/16) butterfly on registers followed by an
+// exchange through LDS; LDS is addressed through an XOR swizzle so that both the strided writes and the
+// contiguous reads of an exchange are (nearly) bank-conflict free without padding; re and im travel
+// separately, so a line needs N * 8 bytes. The row kernels hold one tile per thread; the column kernel
+// holds V = 2 tiles per thread, which makes a workgroup TC = 4 columns wide at H = 4096.
+//
+// Why the column kernel wants wide tiles (measured on MI355X with scripts/trace_col.py, profiles/r01_d_*):
+// the pass is bound by the NUMBER of line requests the memory pipeline takes, not by bytes -- a request
+// that uses 32 of a line's 128 bytes costs as much as one that uses all of them, loads and stores alike
+// (with 2-column tiles 13 of 38 us per tile went into just issuing the spectrum loads). TC adjacent
+// columns are TC*16 contiguous bytes of a spectrum row and TC*8 bytes of a cov / d/dcov row.
 #pragma once
 #include "gpt_common.h"
 #include "gpt_host.h"
+
+#ifndef GPT_TRACE
+#define GPT_TRACE 0
+#endif
+#if GPT_TRACE
+// debug builds only (scripts/trace_col.py): phase timestamps (100 MHz clock) of wave 0 of every column workgroup
+__device__ unsigned long long g_col_trace[1024 * 8 * 8];
+#define TRACE_MARK(r_, k_)                                                                         \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && (r_) < 8)                                                          \
+            g_col_trace[((blockIdx.x & 1023) * 8 + (r_)) * 8 + (k_)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define TRACE_MARK(r_, k_) ((void)0)
+#endif
 
 namespace pow2 {
 
@@ -37,8 +59,12 @@ constexpr int COL_SKEW = 8;
 #else
 #define SCHED_FENCE() ((void)0)
 #endif
-#ifndef GPT_COV_AHEAD
-#define GPT_COV_AHEAD 0
+// register tiles per thread in the column kernel
+#ifndef GPT_COL_V
+#define GPT_COL_V 2
+#endif
+#ifndef GPT_COL_THREADS
+#define GPT_COL_THREADS 512
 #endif
 
 // Timing-only ablation builds (make ABLATE=<bits>): 1 = no butterflies, 2 = no LDS exchanges,
@@ -219,67 +245,97 @@ __device__ __forceinline__ void stage_bfly(cplx (&v)[E], const cplx* w1) {
 
 // Exchange after a (non-final) stage: scatter the butterfly outputs to their Stockham positions, gather
 // back the elements t + T*m the next stage needs. Real and imaginary parts travel separately, so a line
-// needs N * 8 bytes of LDS (32 KB for N = 4096): twice the workgroups fit a CU.
-template <int N, int R, int NS>
-__device__ __forceinline__ void exchange(cplx (&v)[E], int t, double* lds) {
+// needs N * 8 bytes of LDS (32 KB for N = 4096). A thread carries V register tiles (tile k belongs to
+// position t[k] of the line); all of them cross in the same four barrier intervals.
+template <int N, int R, int NS, int V>
+__device__ __forceinline__ void exchange(cplx (&v)[V][E], const int (&t)[V], double* lds) {
     constexpr int T = N / E, U = E / R;
     if (GPT_ABLATE & 2) return;
-    int o0[U];
+    int o0[V][U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int j = t + T * u;
-        o0[u] = (j / NS) * NS * R + (j & (NS - 1));
-    }
+    for (int k = 0; k < V; ++k)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = t[k] + T * u;
+            o0[k][u] = (j / NS) * NS * R + (j & (NS - 1));
+        }
     __syncthreads(); // everyone is done reading the previous contents of this LDS region
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int k = 0; k < V; ++k)
 #pragma unroll
-        for (int p = 0; p < R; ++p) lds[phys(o0[u] + p * NS)] = v[u + p * U].x;
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int p = 0; p < R; ++p) lds[phys(o0[k][u] + p * NS)] = v[k][u + p * U].x;
     __syncthreads();
     // (t + T m) >> 4 & 15 does not depend on m when T is a multiple of 256: one swizzled base + offsets
-    const int rb = phys(t);
 #pragma unroll
-    for (int m = 0; m < E; ++m) v[m].x = lds[(T % 256 == 0) ? rb + T * m : phys(t + T * m)];
+    for (int k = 0; k < V; ++k) {
+        const int rb = phys(t[k]);
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[k][m].x = lds[(T % 256 == 0) ? rb + T * m : phys(t[k] + T * m)];
+    }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int k = 0; k < V; ++k)
 #pragma unroll
-        for (int p = 0; p < R; ++p) lds[phys(o0[u] + p * NS)] = v[u + p * U].y;
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int p = 0; p < R; ++p) lds[phys(o0[k][u] + p * NS)] = v[k][u + p * U].y;
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < E; ++m) v[m].y = lds[(T % 256 == 0) ? rb + T * m : phys(t + T * m)];
+    for (int k = 0; k < V; ++k) {
+        const int rb = phys(t[k]);
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[k][m].y = lds[(T % 256 == 0) ? rb + T * m : phys(t[k] + T * m)];
+    }
 }
 
-template <int N, int NS, int IDX, bool INV>
-__device__ __forceinline__ void fft_rec(cplx (&v)[E], int t, double* lds, const cplx* wpre) {
+template <int N, int NS, int IDX, bool INV, int V>
+__device__ __forceinline__ void fft_rec(cplx (&v)[V][E], const int (&t)[V], double* lds,
+                                        const cplx (&wpre)[V][tw_npre<N>() > 0 ? tw_npre<N>() : 1]) {
     constexpr int REM = N / NS;
     constexpr int R = REM >= 16 ? 16 : REM;
     constexpr int U = E / R;
-    stage_bfly<N, R, NS, INV>(v, wpre + IDX);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        stage_bfly<N, R, NS, INV>(v[k], wpre[k] + IDX);
+        SCHED_FENCE();
+    }
     if constexpr (NS * R < N) {
-        exchange<N, R, NS>(v, t, lds);
-        fft_rec<N, NS * R, IDX + (NS > 1 ? U : 0), INV>(v, t, lds, wpre);
+        exchange<N, R, NS, V>(v, t, lds);
+        fft_rec<N, NS * R, IDX + (NS > 1 ? U : 0), INV, V>(v, t, lds, wpre);
     }
 }
 
-// In: v[m] = x[t + T m]. Out: v[m] = X[t + T m] (natural order). `lds` is this line's region of N doubles,
-// `wpre` the thread's twiddle bases (tw_load).
+// In: v[k][m] = x[t[k] + T m]. Out: v[k][m] = X[t[k] + T m] (natural order). `lds` is this line's region of
+// N doubles, `wpre[k]` the twiddle bases of line position t[k] (tw_load).
+template <int N, bool INV, int V>
+__device__ __forceinline__ void fft_regs(cplx (&v)[V][E], const int (&t)[V], double* lds,
+                                         const cplx (&wpre)[V][tw_npre<N>() > 0 ? tw_npre<N>() : 1]) {
+    fft_rec<N, 1, 0, INV, V>(v, t, lds, wpre);
+}
+
+// one tile per thread (row kernels)
 template <int N, bool INV>
 __device__ __forceinline__ void fft_regs(cplx (&v)[E], int t, double* lds, const cplx* wpre) {
-    fft_rec<N, 1, 0, INV>(v, t, lds, wpre);
+    cplx(&vv)[1][E] = reinterpret_cast<cplx(&)[1][E]>(v);
+    const int tt[1] = {t};
+    cplx w[1][tw_npre<N>() > 0 ? tw_npre<N>() : 1];
+#pragma unroll
+    for (int i = 0; i < tw_npre<N>(); ++i) w[0][i] = wpre[i];
+    fft_rec<N, 1, 0, INV, 1>(vv, tt, lds, w);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Geometry of the workgroups.
 template <int N> struct Geo {
-    static constexpr int T = N / E;                      // threads per line
-    static constexpr int ROW_THREADS = T < 256 ? 256 : T; // row kernels: >= 256 threads
+    static constexpr int T = N / E;                      // register tiles per line
+    static constexpr int ROW_THREADS = T < 256 ? 256 : T; // row kernels: one tile per thread, >= 256 threads
     static constexpr int ROW_LINES = ROW_THREADS / T;     // row pairs per workgroup
-#ifndef GPT_COL_THREADS
-#define GPT_COL_THREADS 512
-#endif
-    static constexpr int COL_THREADS = T < GPT_COL_THREADS ? GPT_COL_THREADS : T; // column kernel
-    static constexpr int TC = COL_THREADS / T;            // adjacent packed columns per workgroup
+    static constexpr int V = GPT_COL_V;                   // column kernel: tiles per thread
+    static constexpr int TP = T / V;                      // ... threads per column
+    static constexpr int COL_THREADS = TP < GPT_COL_THREADS ? GPT_COL_THREADS : TP;
+    static constexpr int TC = COL_THREADS / TP;           // adjacent packed columns per workgroup
 };
 
 // pass A --------------------------------------------------------------------------------------------
@@ -304,13 +360,14 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
     tw_load<W>(wpre, a.pw.tw, t);
     cplx v[E];
 #pragma unroll
-    for (int m = 0; m < E; ++m) v[m] = make_double2(r0[t + T * m], r1[t + T * m]);
+    for (int m = 0; m < E; ++m) // read once: non-temporal, the cache space is worth more to the workspace (-20 us)
+        v[m] = make_double2(__builtin_nontemporal_load(r0 + t + T * m), __builtin_nontemporal_load(r1 + t + T * m));
     if (in_mode == 1 && a.loc) {
         const double* l0 = a.loc + b * a.loc_bs + (int64_t)(2 * rr) * W;
         const double* l1 = l0 + W;
 #pragma unroll
         for (int m = 0; m < E; ++m) {
-            v[m].x -= l0[t + T * m];
+            v[m].x -= l0[t + T * m]; // loc may be shared by the whole batch: ordinary loads
             v[m].y -= l1[t + T * m];
         }
     }
@@ -357,7 +414,8 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
 // out = alpha * value (+ loc when add_loc)
 template <int W>
 __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a, double alpha, int add_loc,
-                                                                      const cplx* __restrict__ ws, int wstride) {
+                                                                      const cplx* __restrict__ ws, int wstride,
+                                                                      FinArgs fin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int T = Geo<W>::T, LINES = Geo<W>::ROW_LINES;
     const int line = threadIdx.x / T, t = threadIdx.x - line * T;
@@ -391,6 +449,11 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
         }
     }
     fft_regs<W, true>(v, t, lds, wpre);
+    if (fin.partials && blockIdx.x == 0) {
+        // the column pass left per-workgroup partials: this workgroup adds them up (saves a launch)
+        __syncthreads();
+        finalize_block(fin, b, reinterpret_cast<double*>(smem));
+    }
     if (!active) return;
     double* o0 = a.out + b * (int64_t)H * W + (int64_t)(2 * rr) * W;
     double* o1 = o0 + W;
@@ -405,27 +468,29 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
     } else {
 #pragma unroll
         for (int m = 0; m < E; ++m) {
-            o0[t + T * m] = alpha * v[m].x;
-            o1[t + T * m] = alpha * v[m].y;
+            __builtin_nontemporal_store(alpha * v[m].x, o0 + t + T * m);
+            __builtin_nontemporal_store(alpha * v[m].y, o1 + t + T * m);
         }
     }
 }
 
 // pass B --------------------------------------------------------------------------------------------
-// Persistent: a workgroup walks over several column tiles (TC adjacent packed columns each) and requests
-// the NEXT tile's spectrum and cov values before it transforms the current one, so HBM / Infinity-Cache
-// traffic overlaps the arithmetic inside one workgroup (the transforms themselves issue no global loads).
+// Persistent: a workgroup walks over several column tiles (TC adjacent packed columns each).
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 labels the XCD),
-// and 8 / TC neighbouring tiles read pieces of the SAME 128-byte lines of the spectrum, of cov and of
-// d/dcov. Each XCD gets a contiguous range of tiles, walked in step by its workgroups, so the sharers meet
-// in one L2 (speed only, never correctness).
+// and 8 / TC neighbouring tiles write pieces of the SAME 128-byte lines of the spectrum and of d/dcov.
+// Each XCD gets a contiguous range of tiles, walked in step by its workgroups, so the pieces meet in one
+// L2 (speed only, never correctness).
+// Thread layout: c = threadIdx % TC (column inside the tile: adjacent lanes -> adjacent columns, so one
+// load instruction reads TC*16 contiguous bytes per row), tp = threadIdx / TC (position in the column);
+// register tile k of the thread sits at line position t[k] = tp + k*TP, i.e. rows t[k] + T*m.
 template <int H, int OP>
 __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, cplx* __restrict__ ws, int wstride,
                                                                      double* __restrict__ partials, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int T = Geo<H>::T, TC = Geo<H>::TC;
+    constexpr int T = Geo<H>::T, TC = Geo<H>::TC, V = Geo<H>::V, TP = Geo<H>::TP;
+    constexpr int NPRE = tw_npre<H>();
     constexpr bool NEEDS_COV = (OP != OP_RFFT2 && OP != OP_INV_RFFT2);
-    const int c = threadIdx.x % TC, t = threadIdx.x / TC;
+    const int c = threadIdx.x % TC, tp = threadIdx.x / TC;
     // adjacent columns' regions are skewed by 8 elements (64 B): the lanes of one LDS lane group alternate
     // between columns, and an unskewed region start would put them on the same banks
     double* lds = reinterpret_cast<double*>(smem) + (size_t)c * (H + COL_SKEW);
@@ -435,8 +500,9 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
     const ZLayout L = make_layout(a);
     const EwPtrs P = make_ptrs(a, b);
     cplx* wsb = ws + (int64_t)b * H * wstride; // uniform base; 32-bit element offsets below
-    cplx wpre[tw_npre<H>()];
-    tw_load<H>(wpre, a.ph.tw, t);
+    cplx wpre[V][NPRE];
+#pragma unroll
+    for (int k = 0; k < V; ++k) tw_load<H>(wpre[k], a.ph.tw, tp + k * TP);
 
     int first, step, count;
     {
@@ -454,99 +520,138 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
     }
     EwAcc acc;
     acc_init(acc);
-    cplx nv[E];
-    double ncv[E];
-    // `tq` is the thread's row index laundered through an empty asm: every address below then depends on
-    // a per-iteration opaque value, which keeps loop-invariant code motion from hoisting ~100 address
-    // registers out of the tile loop (they are cheap to recompute and expensive to keep).
-    auto prefetch = [&](int tile, int tq) {
-        const unsigned jq = (unsigned)(tile * TC + c);
-        if (op_has_fwd(OP)) {
-#pragma unroll
-            for (int m = 0; m < E; ++m) nv[m] = wsb[(unsigned)(tq + T * m) * (unsigned)wstride + jq];
-        }
-        if (NEEDS_COV && GPT_COV_AHEAD) {
-#pragma unroll
-            for (int m = 0; m < E; ++m) ncv[m] = P.cov[(unsigned)(tq + T * m) * (unsigned)L.Wf + jq];
-        }
-    };
-    if (count > 0) prefetch(first, t);
 #pragma unroll 1
     for (int r = 0; r < count; ++r) {
         const int tile = first + r * step;
         const int j0 = tile * TC;
         const int jp = j0 + c; // packed column
-        int tl = t;
-        asm volatile("" : "+v"(tl));
+        // The thread's line positions, laundered through an empty asm: every address below then depends on a
+        // per-iteration opaque value, which keeps loop-invariant code motion from hoisting ~100 address
+        // registers out of the tile loop (they are cheap to recompute and expensive to keep) ...
+        int tl[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            tl[k] = tp + k * TP;
+            asm volatile("" : "+v"(tl[k]));
+        }
         // ... and the twiddle bases: their power trees (60 complex values per tile) would otherwise be
         // hoisted out of the loop and parked in scratch memory.
-        cplx wl[tw_npre<H>()];
+        cplx wl[V][NPRE];
 #pragma unroll
-        for (int i = 0; i < tw_npre<H>(); ++i) {
-            wl[i] = wpre[i];
-            asm volatile("" : "+v"(wl[i].x), "+v"(wl[i].y));
-        }
-        cplx v[E];
-        double cv[E];
+        for (int k = 0; k < V; ++k)
 #pragma unroll
-        for (int m = 0; m < E; ++m) {
-            v[m] = op_has_fwd(OP) ? nv[m] : make_double2(0.0, 0.0);
-            cv[m] = (NEEDS_COV && GPT_COV_AHEAD) ? ncv[m] : 1.0;
-        }
-        if (r + 1 < count) prefetch(tile + step, tl);
-        if (op_has_fwd(OP)) fft_regs<H, false>(v, tl, lds, wl);
+            for (int i = 0; i < NPRE; ++i) {
+                wl[k][i] = wpre[k][i];
+                asm volatile("" : "+v"(wl[k][i].x), "+v"(wl[k][i].y));
+            }
+        cplx v[V][E];
+        TRACE_MARK(r, 0);
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+#pragma unroll
+            for (int m = 0; m < E; ++m)
+                v[k][m] = op_has_fwd(OP) ? wsb[(unsigned)(tl[k] + T * m) * (unsigned)wstride + (unsigned)jp]
+                                         : make_double2(0.0, 0.0);
+#if GPT_TRACE
+        TRACE_MARK(r, 1); // loads issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        TRACE_MARK(r, 2); // ... and arrived
         const bool own0 = (j0 == 0); // workgroup-uniform: this tile holds the packed column 0
+        // its first cov values are requested before the transform: when the other workgroups are in their
+        // elementwise stage a load takes >10 us, and this workgroup is the one the kernel waits for
+        EdgeCov ec = {1.0, 1.0, 1.0, 1.0}, en = ec;
+        if (own0) {
+            const int k0 = threadIdx.x, k1 = k0 + Geo<H>::COL_THREADS;
+            ec = load_edge_cov<OP>(a, L, P, k0 <= H / 2 ? k0 : 0);
+            en = load_edge_cov<OP>(a, L, P, k1 <= H / 2 ? k1 : 0);
+        }
+        if (op_has_fwd(OP)) fft_regs<H, false, V>(v, tl, lds, wl);
+        TRACE_MARK(r, 3);
         if (own0) {
             // Packed column 0 (DC + i*Nyquist): rows k and H-k must meet, so the column goes through LDS
-            // and is processed by a ROLLED loop (few registers, little code; one column out of W/2).
+            // and is processed by a ROLLED loop (few registers, little code; one column out of W/2) that
+            // requests the next row's cov values before it works on the current row.
+            TRACE_MARK(7, 0);
             __syncthreads();
             if (c == 0) {
 #pragma unroll
-                for (int m = 0; m < E; ++m) lds0[phys(tl + T * m)] = v[m];
+                for (int k = 0; k < V; ++k)
+#pragma unroll
+                    for (int m = 0; m < E; ++m) lds0[phys(tl[k] + T * m)] = v[k][m];
             }
             __syncthreads();
+            TRACE_MARK(7, 1);
 #pragma unroll 1
-            for (int k = threadIdx.x; k <= H / 2; k += Geo<H>::COL_THREADS) {
-                const bool self = (k == 0) || (k == H / 2);
-                cplx Zk = lds0[phys(k)];
-                cplx Zm = self ? Zk : lds0[phys(H - k)];
-                ew_packed0<OP>(a, L, P, k, Zk, Zm, acc);
+            for (int kk = threadIdx.x; kk <= H / 2; kk += Geo<H>::COL_THREADS) {
+                const int kn = kk + 2 * Geo<H>::COL_THREADS;
+                const EdgeCov e2 = load_edge_cov<OP>(a, L, P, kn <= H / 2 ? kn : 0);
+                const bool self = (kk == 0) || (kk == H / 2);
+                cplx Zk = lds0[phys(kk)];
+                cplx Zm = self ? Zk : lds0[phys(H - kk)];
+                ew_packed0_c<OP>(a, L, P, kk, Zk, Zm, ec, acc);
                 if (op_has_inv(OP)) {
-                    lds0[phys(k)] = Zk;
-                    if (!self) lds0[phys(H - k)] = Zm;
+                    lds0[phys(kk)] = Zk;
+                    if (!self) lds0[phys(H - kk)] = Zm;
                 }
+                ec = en;
+                en = e2;
+                TRACE_MARK(7, 2 + kk / Geo<H>::COL_THREADS);
             }
             __syncthreads();
+            TRACE_MARK(7, 7);
             if (c == 0 && op_has_inv(OP)) {
 #pragma unroll
-                for (int m = 0; m < E; ++m) v[m] = lds0[phys(tl + T * m)];
+                for (int k = 0; k < V; ++k)
+#pragma unroll
+                    for (int m = 0; m < E; ++m) v[k][m] = lds0[phys(tl[k] + T * m)];
             }
             __syncthreads();
         }
         if (!(own0 && c == 0) && !(GPT_ABLATE & 4)) {
-            if (NEEDS_COV && !GPT_COV_AHEAD) {
+            // one register tile at a time: its 16 cov values are requested together, then consumed
 #pragma unroll
-                for (int m = 0; m < E; ++m) cv[m] = P.cov[(unsigned)(tl + T * m) * (unsigned)L.Wf + (unsigned)jp];
-            }
+            for (int k = 0; k < V; ++k) {
+                double cv[E];
 #pragma unroll
-            for (int m = 0; m < E; ++m) {
-                v[m] = ew_interior_c<OP>(a, L, P, tl + T * m, jp, v[m], cv[m], acc);
-                if ((m & 3) == 3) SCHED_FENCE();
+                for (int m = 0; m < E; ++m)
+                    cv[m] = NEEDS_COV ? P.cov[(unsigned)(tl[k] + T * m) * (unsigned)L.Wf + (unsigned)jp] : 1.0;
+#if GPT_TRACE
+                if (k == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    TRACE_MARK(r, 4);
+                }
+#endif
+#pragma unroll
+                for (int m = 0; m < E; ++m) {
+                    v[k][m] = ew_interior_c<OP>(a, L, P, tl[k] + T * m, jp, v[k][m], cv[m], acc);
+                    if ((m & 3) == 3) SCHED_FENCE();
+                }
             }
         }
         acc_fold(acc);
         __builtin_amdgcn_sched_barrier(0);
+        TRACE_MARK(r, 5);
         if (op_has_inv(OP)) {
-            // Launder the thread index all LDS addresses derive from, tied to a value the elementwise stage
+            // Launder the line positions all LDS addresses derive from, tied to a value the elementwise stage
             // produced: otherwise the compiler keeps the forward transform's addresses alive to reuse them
             // here, or schedules parts of the inverse transform above the elementwise stage (spills).
-            int t_inv = tl;
-            asm volatile("" : "+v"(t_inv), "+v"(v[0].x));
+            int t_inv[V];
 #pragma unroll
-            for (int i = 0; i < tw_npre<H>(); ++i) asm volatile("" : "+v"(wl[i].x), "+v"(wl[i].y), "+v"(v[0].x));
-            fft_regs<H, true>(v, t_inv, lds, wl);
+            for (int k = 0; k < V; ++k) {
+                t_inv[k] = tl[k];
+                asm volatile("" : "+v"(t_inv[k]), "+v"(v[0][0].x));
 #pragma unroll
-            for (int m = 0; m < E; ++m) wsb[(unsigned)(t_inv + T * m) * (unsigned)wstride + (unsigned)jp] = v[m];
+                for (int i = 0; i < NPRE; ++i) asm volatile("" : "+v"(wl[k][i].x), "+v"(wl[k][i].y), "+v"(v[0][0].x));
+            }
+            fft_regs<H, true, V>(v, t_inv, lds, wl);
+            TRACE_MARK(r, 6);
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+#pragma unroll
+                for (int m = 0; m < E; ++m)
+                    wsb[(unsigned)(t_inv[k] + T * m) * (unsigned)wstride + (unsigned)jp] = v[k][m];
+            TRACE_MARK(r, 7);
         }
     }
     if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
@@ -564,7 +669,7 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
 template <int N> struct Launch {
     static hipError_t row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, hipStream_t st);
     static hipError_t row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
-                              hipStream_t st);
+                              const FinArgs& fin, hipStream_t st);
     static hipError_t col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, hipStream_t st);
     // grid of the persistent column kernel = number of per-lattice partials
     static int col_blocks(int W) {

@@ -34,14 +34,14 @@ hipError_t Launch<GPT_N>::row_fwd(const LatArgs& a, int in_mode, cplx* ws, int w
 
 template <>
 hipError_t Launch<GPT_N>::row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
-                                  hipStream_t st) {
+                                  const FinArgs& fin, hipStream_t st) {
     constexpr int W = GPT_N;
     const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(double);
     hipError_t e = raise_lds(row_inv_kernel<W>, lds);
     if (e != hipSuccess) return e;
     const int npairs = a.H / 2;
     dim3 grid((npairs + Geo<W>::ROW_LINES - 1) / Geo<W>::ROW_LINES, (unsigned)a.batch);
-    hipLaunchKernelGGL(row_inv_kernel<W>, grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, alpha, add_loc, ws, wstride);
+    hipLaunchKernelGGL(row_inv_kernel<W>, grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, alpha, add_loc, ws, wstride, fin);
     return hipGetLastError();
 }
 
@@ -75,3 +75,12 @@ hipError_t Launch<GPT_N>::col(int op, const LatArgs& a, cplx* ws, int wstride, d
 }
 
 } // namespace pow2
+
+#if GPT_TRACE
+// debug builds only: copy the column kernel's phase timestamps to the host (scripts/trace_col.py)
+extern "C" int gpt_debug_col_trace(unsigned long long* dst, size_t n) {
+    if (n > sizeof(g_col_trace) / sizeof(g_col_trace[0])) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_col_trace), n * sizeof(unsigned long long));
+}
+#endif
