@@ -119,9 +119,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ctx = fft.get_context(device)
     for _ in range(args.warmup):
         step()
-    ctx = fft.get_context(device)
     barrier()
     profile = not args.no_profile
     if profile:

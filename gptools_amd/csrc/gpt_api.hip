@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -26,8 +27,13 @@ struct gpt_ctx {
     double* pinned = nullptr; // small pinned scratch for scalar read-backs
     std::string err;
     double last_min_eig = NAN;
-    bool profiling = false;              // record events around the passes of the three-pass paths
-    std::vector<hipEvent_t> prof_events; // 5 per chunk launch
+    bool profiling = false; // record events around the passes of the three-pass paths
+    struct ProfRec {
+        hipEvent_t t0, t1;
+        int pass; // 0 = A, 1 = B, 3 = C (slot 2 is the separate finalize of older builds: always 0 now)
+    };
+    std::vector<ProfRec> prof;
+    int total_cus = 0;
 };
 
 namespace {
@@ -138,14 +144,22 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
         snprintf(buf, sizeof buf, "no kernel for a %d x %d lattice in this build", a.H, a.W);
         return fail(c, GPT_ERR_UNSUPPORTED, buf);
     }
-    // Three-pass paths: lattices are processed in chunks that share one packed-spectrum workspace, kept
-    // small enough (<= ~128 MiB) to stay resident in the 256 MiB Infinity Cache between the passes.
+    // Three-pass paths: lattices are processed in units (chunks of lattices that share one packed-spectrum
+    // workspace of <= ~128 MiB, so that it can live in the 256 MiB Infinity Cache between the passes), one
+    // unit after the other on the context's stream. (Overlapping pass B of one lattice with the row passes of
+    // its neighbours on a second stream, with and without CU masks, was measured and is slower: pass B has no
+    // idle CU resources to share and slows down in proportion to the CUs it gives up -- DESIGN.md section 6.)
     const size_t per = path == 1 ? gpt_pow2_workspace_bytes(a.H, a.W) : gpt_generic_workspace_bytes(a.H, a.W);
-    const int nblk = path == 1 ? gpt_pow2_col_blocks(a.H, a.W) : gpt_generic_col_blocks(a.H, a.W);
     int64_t chunk = (int64_t)((size_t)(128u << 20) / per);
     if (chunk < 1) chunk = 1;
     if (chunk > a.batch) chunk = a.batch;
     if (chunk > 32768) chunk = 32768;
+    if (c->total_cus == 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+        c->total_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int nblk = path == 1 ? gpt_pow2_col_blocks(a.H, a.W, c->total_cus) : gpt_generic_col_blocks(a.H, a.W);
     if ((rc = ensure(c, c->ws, c->ws_bytes, per * (size_t)chunk)) != GPT_OK) return rc;
     if ((rc = ensure(c, c->partials, c->partials_bytes, sizeof(double) * GPT_PART * (size_t)nblk * (size_t)chunk)) !=
         GPT_OK)
@@ -164,15 +178,25 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
         if (s.out_c) s.out_c += b0 * hwf;
         if (s.out_lpdf) s.out_lpdf += b0;
         if (s.min_eig) s.min_eig += b0;
-        hipEvent_t* ev = nullptr;
-        if (c->profiling) {
-            const size_t at = c->prof_events.size();
-            c->prof_events.resize(at + 5);
-            for (int i = 0; i < 5; ++i) HIP_TRY(c, hipEventCreate(&c->prof_events[at + i]));
-            ev = &c->prof_events[at];
+        if (path != 1) {
+            HIP_TRY(c, gpt_launch_generic(op, s, c->ws, c->partials, c->stream));
+            continue;
         }
-        if (path == 1) HIP_TRY(c, gpt_launch_pow2(op, s, c->ws, c->partials, c->stream, ev));
-        else HIP_TRY(c, gpt_launch_generic(op, s, c->ws, c->partials, c->stream));
+        for (int pass = 0; pass < 3; ++pass) {
+            // each pass bracketed by timing events in profiling mode
+            const bool present = pass == 1 || (pass == 0 ? op_has_fwd(op) : op_has_inv(op));
+            gpt_ctx::ProfRec pr = {nullptr, nullptr, pass == 2 ? 3 : pass};
+            if (c->profiling && present) {
+                HIP_TRY(c, hipEventCreate(&pr.t0));
+                HIP_TRY(c, hipEventCreate(&pr.t1));
+                HIP_TRY(c, hipEventRecord(pr.t0, c->stream));
+            }
+            HIP_TRY(c, gpt_pow2_pass(pass, op, s, c->ws, c->partials, c->total_cus, c->stream));
+            if (pr.t0) {
+                HIP_TRY(c, hipEventRecord(pr.t1, c->stream));
+                c->prof.push_back(pr);
+            }
+        }
     }
     return GPT_OK;
 }
@@ -260,7 +284,10 @@ int gpt_destroy(gpt_ctx* c) {
     if (!c) return GPT_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+    for (auto& r : c->prof) {
+        (void)hipEventDestroy(r.t0);
+        (void)hipEventDestroy(r.t1);
+    }
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     if (c->ws) (void)hipFree(c->ws);
     if (c->partials) (void)hipFree(c->partials);
@@ -288,8 +315,11 @@ int gpt_synchronize(gpt_ctx* c) {
 
 int gpt_profile_begin(gpt_ctx* c) {
     if (!c) return GPT_ERR_SHAPE;
-    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
-    c->prof_events.clear();
+    for (auto& r : c->prof) {
+        (void)hipEventDestroy(r.t0);
+        (void)hipEventDestroy(r.t1);
+    }
+    c->prof.clear();
     c->profiling = true;
     return GPT_OK;
 }
@@ -300,18 +330,21 @@ int gpt_profile_end(gpt_ctx* c, double* pass_ms, int64_t* launches) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     double acc[4] = {0, 0, 0, 0};
-    const size_t n = c->prof_events.size() / 5;
-    for (size_t i = 0; i < n; ++i)
-        for (int k = 0; k < 4; ++k) {
-            float ms = 0.f;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_events[5 * i + k], c->prof_events[5 * i + k + 1]));
-            acc[k] += ms;
-        }
-    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
-    c->prof_events.clear();
+    int64_t nb = 0;
+    for (auto& r : c->prof) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, r.t0, r.t1));
+        acc[r.pass] += ms;
+        if (r.pass == 1) ++nb;
+    }
+    for (auto& r : c->prof) {
+        (void)hipEventDestroy(r.t0);
+        (void)hipEventDestroy(r.t1);
+    }
+    c->prof.clear();
     if (pass_ms)
         for (int k = 0; k < 4; ++k) pass_ms[k] = acc[k];
-    if (launches) *launches = (int64_t)n;
+    if (launches) *launches = nb;
     return GPT_OK;
 }
 

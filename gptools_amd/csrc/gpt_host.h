@@ -12,10 +12,13 @@ hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st);
 #define GPT_WS_PAD 8
 bool gpt_pow2_supported(int H, int W);
 size_t gpt_pow2_workspace_bytes(int H, int W);
-int gpt_pow2_col_blocks(int H, int W);
-// `ev` (may be null): 5 events recorded before pass A, after pass A, after pass B, after the finalize
-// kernel and after pass C (profiling mode of the context).
-hipError_t gpt_launch_pow2(int op, const LatArgs& a, cplx* ws, double* partials, hipStream_t st, hipEvent_t* ev);
+// Workgroups of the persistent column kernel (= partials per lattice) when it may use `cus` CUs.
+int gpt_pow2_col_blocks(int H, int W, int cus);
+// One pass of the three: 0 = row forward (A), 1 = column (B; plus the second reduction stage when the op has
+// no pass C), 2 = row inverse (C; sums B's partials). A pass the op does not have is a no-op. `col_cus`
+// must be the same for the three passes of one lattice.
+hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* partials, int col_cus,
+                         hipStream_t st);
 
 // --- generic large path (gpt_generic.hip): any H, W whose lines fit LDS
 bool gpt_generic_supported(int H, int W);

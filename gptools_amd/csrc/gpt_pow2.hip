@@ -21,57 +21,53 @@ bool gpt_pow2_supported(int H, int W) { return is_pow2_in_range(H) && is_pow2_in
 
 size_t gpt_pow2_workspace_bytes(int H, int W) { return (size_t)H * (size_t)(W / 2 + GPT_WS_PAD) * sizeof(cplx); }
 
-int gpt_pow2_col_blocks(int H, int W) {
+int gpt_pow2_col_blocks(int H, int W, int cus) {
     int nb = 1;
     (void)by_size(H, [&](auto l) {
-        nb = decltype(l)::col_blocks(W);
+        nb = decltype(l)::col_blocks(W, cus);
         return hipSuccess;
     });
     return nb;
 }
 
-hipError_t gpt_launch_pow2(int op, const LatArgs& a, cplx* ws, double* partials, hipStream_t st, hipEvent_t* ev) {
+hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* partials, int col_cus,
+                         hipStream_t st) {
     if (!gpt_pow2_supported(a.H, a.W)) return hipErrorInvalidValue;
     const int wstride = a.W / 2 + GPT_WS_PAD;
     const double n = (double)a.H * (double)a.W;
-    hipError_t e = hipSuccess;
-    auto mark = [&](int i) {
-        if (ev) (void)hipEventRecord(ev[i], st);
-    };
-    mark(0);
-    if (op_has_fwd(op)) {
+    const int nblk = gpt_pow2_col_blocks(a.H, a.W, col_cus);
+    const bool reduces = (op != OP_RFFT2 && op != OP_INV_RFFT2);
+    const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op));
+    const double add = -0.5 * n * 1.8378770664093454836;
+    if (pass == 0) {
+        if (!op_has_fwd(op)) return hipSuccess;
         const int in_mode = op == OP_RFFT2 ? 0 : (op == OP_INV_VJP ? 2 : 1);
-        e = by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, in_mode, ws, wstride, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, in_mode, ws, wstride, st); });
+    }
+    if (pass == 1) {
+        hipError_t e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, ws, wstride, partials, nblk, st); });
         if (e != hipSuccess) return e;
+        // second reduction stage: folded into pass C when there is one
+        if (reduces && !op_has_inv(op))
+            e = gpt_launch_finalize(partials, nblk, a.batch, 1, add, lp ? a.out_lpdf : nullptr, a.min_eig, st);
+        return e;
     }
-    mark(1);
-    e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, ws, wstride, partials, st); });
-    if (e != hipSuccess) return e;
-    mark(2);
-    // second reduction stage of the column pass: folded into pass C when there is one
-    FinArgs fin = {nullptr, 0, 0.0, nullptr, nullptr};
-    if (op != OP_RFFT2 && op != OP_INV_RFFT2) {
-        const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op));
-        fin.partials = partials;
-        fin.nblk = gpt_pow2_col_blocks(a.H, a.W);
-        fin.add = -0.5 * n * 1.8378770664093454836;
-        fin.out_sum = lp ? a.out_lpdf : nullptr;
-        fin.out_min = a.min_eig;
-        if (!op_has_inv(op)) {
-            e = gpt_launch_finalize(partials, fin.nblk, a.batch, 1, fin.add, fin.out_sum, fin.out_min, st);
-            if (e != hipSuccess) return e;
-            fin.partials = nullptr;
+    if (pass == 2) {
+        if (!op_has_inv(op)) return hipSuccess;
+        FinArgs fin = {nullptr, 0, 0.0, nullptr, nullptr};
+        if (reduces) {
+            fin.partials = partials;
+            fin.nblk = nblk;
+            fin.add = add;
+            fin.out_sum = lp ? a.out_lpdf : nullptr;
+            fin.out_min = a.min_eig;
         }
-    }
-    mark(3);
-    if (op_has_inv(op)) {
         double alpha = 1.0;
         int add_loc = 0;
         if (op == OP_INV_RFFT2) alpha = 1.0 / n;
         else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
         else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
-        e = by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, fin, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, fin, st); });
     }
-    mark(4);
-    return e;
+    return hipErrorInvalidValue;
 }

@@ -670,11 +670,13 @@ template <int N> struct Launch {
     static hipError_t row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, hipStream_t st);
     static hipError_t row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
                               const FinArgs& fin, hipStream_t st);
-    static hipError_t col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, hipStream_t st);
-    // grid of the persistent column kernel = number of per-lattice partials
-    static int col_blocks(int W) {
+    static hipError_t col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg, hipStream_t st);
+    // grid of the persistent column kernel = number of per-lattice partials, one workgroup per CU it may use
+    static int col_blocks(int W, int cus) {
         const int ntiles = (W / 2) / Geo<N>::TC;
-        const int cap = 256 * GPT_COL_WGS_PER_CU;
+        int cap = cus * GPT_COL_WGS_PER_CU;
+        if (cap >= 8) cap &= ~7; // multiples of 8 keep the XCD-aware tile order
+        if (cap < 1) cap = 1;
         return ntiles < cap ? ntiles : cap;
     }
 };

@@ -46,30 +46,31 @@ hipError_t Launch<GPT_N>::row_inv(const LatArgs& a, double alpha, int add_loc, c
 }
 
 template <int OP>
-static hipError_t col_t(const LatArgs& a, cplx* ws, int wstride, double* partials, hipStream_t st) {
+static hipError_t col_t(const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg, hipStream_t st) {
     constexpr int H = GPT_N;
     const size_t lds = col_lds_bytes<H>();
     hipError_t e = raise_lds(col_kernel<H, OP>, lds);
     if (e != hipSuccess) return e;
     const int ntiles = (a.W / 2) / Geo<H>::TC;
-    dim3 grid(Launch<H>::col_blocks(a.W), (unsigned)a.batch);
+    dim3 grid((unsigned)nwg, (unsigned)a.batch);
     hipLaunchKernelGGL((col_kernel<H, OP>), grid, dim3(Geo<H>::COL_THREADS), lds, st, a, ws, wstride, partials,
                        ntiles);
     return hipGetLastError();
 }
 
 template <>
-hipError_t Launch<GPT_N>::col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, hipStream_t st) {
+hipError_t Launch<GPT_N>::col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg,
+                              hipStream_t st) {
     switch (op) {
-    case OP_RFFT2: return col_t<OP_RFFT2>(a, ws, wstride, partials, st);
-    case OP_INV_RFFT2: return col_t<OP_INV_RFFT2>(a, ws, wstride, partials, st);
-    case OP_GP_RFFT2: return col_t<OP_GP_RFFT2>(a, ws, wstride, partials, st);
-    case OP_GP_INV_RFFT2: return col_t<OP_GP_INV_RFFT2>(a, ws, wstride, partials, st);
-    case OP_LPDF: return col_t<OP_LPDF>(a, ws, wstride, partials, st);
-    case OP_LPDF_VJP: return col_t<OP_LPDF_VJP>(a, ws, wstride, partials, st);
-    case OP_INV_VJP: return col_t<OP_INV_VJP>(a, ws, wstride, partials, st);
-    case OP_FWD_VJP: return col_t<OP_FWD_VJP>(a, ws, wstride, partials, st);
-    case OP_LPDF_VJP_NOCOV: return col_t<OP_LPDF_VJP_NOCOV>(a, ws, wstride, partials, st);
+    case OP_RFFT2: return col_t<OP_RFFT2>(a, ws, wstride, partials, nwg, st);
+    case OP_INV_RFFT2: return col_t<OP_INV_RFFT2>(a, ws, wstride, partials, nwg, st);
+    case OP_GP_RFFT2: return col_t<OP_GP_RFFT2>(a, ws, wstride, partials, nwg, st);
+    case OP_GP_INV_RFFT2: return col_t<OP_GP_INV_RFFT2>(a, ws, wstride, partials, nwg, st);
+    case OP_LPDF: return col_t<OP_LPDF>(a, ws, wstride, partials, nwg, st);
+    case OP_LPDF_VJP: return col_t<OP_LPDF_VJP>(a, ws, wstride, partials, nwg, st);
+    case OP_INV_VJP: return col_t<OP_INV_VJP>(a, ws, wstride, partials, nwg, st);
+    case OP_FWD_VJP: return col_t<OP_FWD_VJP>(a, ws, wstride, partials, nwg, st);
+    case OP_LPDF_VJP_NOCOV: return col_t<OP_LPDF_VJP_NOCOV>(a, ws, wstride, partials, nwg, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -62,10 +62,10 @@ const char* gpt_last_error(const gpt_ctx* ctx);
 double gpt_last_min_eig(const gpt_ctx* ctx);
 const char* gpt_version(void);
 /* Measurement aid (no counterpart in the reference): between gpt_profile_begin and gpt_profile_end the
- * three-pass paths bracket each pass of every launch with HIP events on the context's stream.
- * gpt_profile_end synchronises and returns the summed durations in milliseconds: pass_ms[0] row
- * transforms (pass A), [1] column pass (B), [2] finalize (reduction), [3] inverse row transforms (C), and
- * the number of per-chunk launch groups they were summed over. */
+ * power-of-two three-pass path brackets each pass of every launch with HIP events on the stream the pass
+ * runs on. gpt_profile_end synchronises and returns the summed durations in milliseconds: pass_ms[0] row
+ * transforms (pass A), [1] column pass (B), [2] unused (0), [3] inverse row transforms (C; includes the
+ * second reduction stage), and the number of column-pass launches they were summed over. */
 int gpt_profile_begin(gpt_ctx* ctx);
 int gpt_profile_end(gpt_ctx* ctx, double* pass_ms, int64_t* launches);
 /* Which kernel family a lattice shape runs on: 0 small (one workgroup per lattice, any H/W),
