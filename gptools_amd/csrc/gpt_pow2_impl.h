@@ -44,7 +44,6 @@ __device__ unsigned long long g_col_trace[1024 * 8 * 8];
 namespace pow2 {
 
 constexpr int E = 16;
-constexpr int COL_SKEW = 8;
 #ifndef GPT_COL_WGS_PER_CU
 #define GPT_COL_WGS_PER_CU 1
 #endif
@@ -73,7 +72,21 @@ constexpr int COL_SKEW = 8;
 #define GPT_ABLATE 0
 #endif
 
-__device__ __forceinline__ int phys(int o) { return o ^ ((o >> 4) & 15); }
+// LDS address swizzle of a line (index in doubles). Mode 0: XOR the low four bits with the next four. The
+// LDS serves a ds_read_b64 in two groups of 32 lanes over 64 four-byte banks and a ds_write_b64 in four
+// groups of 16 lanes over 32 banks (MI355X_MICROARCH.md, LDS): one line per 16/32 consecutive lanes is
+// conflict free with mode 0. Mode 1 (column kernel, 4 interleaved columns: a read group is 8 positions x 4
+// columns, a write group 4 x 4) additionally swaps address bits 2 and 4, so that 8 consecutive positions
+// land in two 4-element runs 16 elements apart; with the columns' regions skewed by 4 elements both the
+// read and the write groups then touch every bank once.
+template <int MODE = 0> __device__ __forceinline__ int phys(int o) {
+    int q = o ^ ((o >> 4) & 15);
+    if (MODE == 1) {
+        const int d = ((q >> 2) ^ (q >> 4)) & 1;
+        q ^= (d << 2) | (d << 4);
+    }
+    return q;
+}
 
 template <bool INV> __device__ __forceinline__ cplx tw_dir(cplx w) {
     if (INV) w.y = -w.y;
@@ -247,7 +260,7 @@ __device__ __forceinline__ void stage_bfly(cplx (&v)[E], const cplx* w1) {
 // back the elements t + T*m the next stage needs. Real and imaginary parts travel separately, so a line
 // needs N * 8 bytes of LDS (32 KB for N = 4096). A thread carries V register tiles (tile k belongs to
 // position t[k] of the line); all of them cross in the same four barrier intervals.
-template <int N, int R, int NS, int V>
+template <int N, int R, int NS, int V, int SWZ>
 __device__ __forceinline__ void exchange(cplx (&v)[V][E], const int (&t)[V], double* lds) {
     constexpr int T = N / E, U = E / R;
     if (GPT_ABLATE & 2) return;
@@ -265,14 +278,14 @@ __device__ __forceinline__ void exchange(cplx (&v)[V][E], const int (&t)[V], dou
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int p = 0; p < R; ++p) lds[phys(o0[k][u] + p * NS)] = v[k][u + p * U].x;
+            for (int p = 0; p < R; ++p) lds[phys<SWZ>(o0[k][u] + p * NS)] = v[k][u + p * U].x;
     __syncthreads();
     // (t + T m) >> 4 & 15 does not depend on m when T is a multiple of 256: one swizzled base + offsets
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-        const int rb = phys(t[k]);
+        const int rb = phys<SWZ>(t[k]);
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[k][m].x = lds[(T % 256 == 0) ? rb + T * m : phys(t[k] + T * m)];
+        for (int m = 0; m < E; ++m) v[k][m].x = lds[(T % 256 == 0) ? rb + T * m : phys<SWZ>(t[k] + T * m)];
     }
     __syncthreads();
 #pragma unroll
@@ -280,39 +293,46 @@ __device__ __forceinline__ void exchange(cplx (&v)[V][E], const int (&t)[V], dou
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int p = 0; p < R; ++p) lds[phys(o0[k][u] + p * NS)] = v[k][u + p * U].y;
+            for (int p = 0; p < R; ++p) lds[phys<SWZ>(o0[k][u] + p * NS)] = v[k][u + p * U].y;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-        const int rb = phys(t[k]);
+        const int rb = phys<SWZ>(t[k]);
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[k][m].y = lds[(T % 256 == 0) ? rb + T * m : phys(t[k] + T * m)];
+        for (int m = 0; m < E; ++m) v[k][m].y = lds[(T % 256 == 0) ? rb + T * m : phys<SWZ>(t[k] + T * m)];
     }
 }
 
-template <int N, int NS, int IDX, bool INV, int V>
+template <int N, int NS, int IDX, bool INV, int V, int SWZ>
 __device__ __forceinline__ void fft_rec(cplx (&v)[V][E], const int (&t)[V], double* lds,
                                         const cplx (&wpre)[V][tw_npre<N>() > 0 ? tw_npre<N>() : 1]) {
     constexpr int REM = N / NS;
     constexpr int R = REM >= 16 ? 16 : REM;
     constexpr int U = E / R;
+#if GPT_TRACE
+    constexpr int SIDX = NS == 1 ? 0 : (NS == 16 ? 1 : 2); // stage number (radix-16 plans)
+    if (!INV && V > 1) TRACE_MARK(6, 2 * SIDX);
+#endif
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         stage_bfly<N, R, NS, INV>(v[k], wpre[k] + IDX);
         SCHED_FENCE();
     }
+#if GPT_TRACE
+    if (!INV && V > 1) TRACE_MARK(6, 2 * SIDX + 1);
+#endif
     if constexpr (NS * R < N) {
-        exchange<N, R, NS, V>(v, t, lds);
-        fft_rec<N, NS * R, IDX + (NS > 1 ? U : 0), INV, V>(v, t, lds, wpre);
+        exchange<N, R, NS, V, SWZ>(v, t, lds);
+        fft_rec<N, NS * R, IDX + (NS > 1 ? U : 0), INV, V, SWZ>(v, t, lds, wpre);
     }
 }
 
 // In: v[k][m] = x[t[k] + T m]. Out: v[k][m] = X[t[k] + T m] (natural order). `lds` is this line's region of
 // N doubles, `wpre[k]` the twiddle bases of line position t[k] (tw_load).
-template <int N, bool INV, int V>
+template <int N, bool INV, int V, int SWZ>
 __device__ __forceinline__ void fft_regs(cplx (&v)[V][E], const int (&t)[V], double* lds,
                                          const cplx (&wpre)[V][tw_npre<N>() > 0 ? tw_npre<N>() : 1]) {
-    fft_rec<N, 1, 0, INV, V>(v, t, lds, wpre);
+    fft_rec<N, 1, 0, INV, V, SWZ>(v, t, lds, wpre);
 }
 
 // one tile per thread (row kernels)
@@ -323,7 +343,7 @@ __device__ __forceinline__ void fft_regs(cplx (&v)[E], int t, double* lds, const
     cplx w[1][tw_npre<N>() > 0 ? tw_npre<N>() : 1];
 #pragma unroll
     for (int i = 0; i < tw_npre<N>(); ++i) w[0][i] = wpre[i];
-    fft_rec<N, 1, 0, INV, 1>(vv, tt, lds, w);
+    fft_rec<N, 1, 0, INV, 1, 0>(vv, tt, lds, w);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -336,6 +356,8 @@ template <int N> struct Geo {
     static constexpr int TP = T / V;                      // ... threads per column
     static constexpr int COL_THREADS = TP < GPT_COL_THREADS ? GPT_COL_THREADS : TP;
     static constexpr int TC = COL_THREADS / TP;           // adjacent packed columns per workgroup
+    static constexpr int SWZ = TC == 4 ? 1 : 0;           // LDS swizzle mode of the column kernel (phys)
+    static constexpr int SKEW = TC == 4 ? 4 : 8;          // ... and the offset between its columns' regions
 };
 
 // pass A --------------------------------------------------------------------------------------------
@@ -493,7 +515,7 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
     const int c = threadIdx.x % TC, tp = threadIdx.x / TC;
     // adjacent columns' regions are skewed by 8 elements (64 B): the lanes of one LDS lane group alternate
     // between columns, and an unskewed region start would put them on the same banks
-    double* lds = reinterpret_cast<double*>(smem) + (size_t)c * (H + COL_SKEW);
+    double* lds = reinterpret_cast<double*>(smem) + (size_t)c * (H + Geo<H>::SKEW);
     cplx* lds0 = reinterpret_cast<cplx*>(smem);    // whole buffer as one complex column (packed column 0)
     double* red = reinterpret_cast<double*>(smem); // reused after the FFTs are done with LDS
     const int64_t b = blockIdx.y;
@@ -566,7 +588,7 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
             ec = load_edge_cov<OP>(a, L, P, k0 <= H / 2 ? k0 : 0);
             en = load_edge_cov<OP>(a, L, P, k1 <= H / 2 ? k1 : 0);
         }
-        if (op_has_fwd(OP)) fft_regs<H, false, V>(v, tl, lds, wl);
+        if (op_has_fwd(OP)) fft_regs<H, false, V, Geo<H>::SWZ>(v, tl, lds, wl);
         TRACE_MARK(r, 3);
         if (own0) {
             // Packed column 0 (DC + i*Nyquist): rows k and H-k must meet, so the column goes through LDS
@@ -644,7 +666,7 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
 #pragma unroll
                 for (int i = 0; i < NPRE; ++i) asm volatile("" : "+v"(wl[k][i].x), "+v"(wl[k][i].y), "+v"(v[0][0].x));
             }
-            fft_regs<H, true, V>(v, t_inv, lds, wl);
+            fft_regs<H, true, V, Geo<H>::SWZ>(v, t_inv, lds, wl);
             TRACE_MARK(r, 6);
 #pragma unroll
             for (int k = 0; k < V; ++k)

@@ -10,7 +10,7 @@ namespace pow2 {
 namespace {
 // split exchange: TC regions of (H + skew) doubles; the packed column 0 needs H complex values once
 template <int H> constexpr size_t col_lds_bytes() {
-    const size_t a = (size_t)Geo<H>::TC * (H + COL_SKEW) * sizeof(double), b = (size_t)H * sizeof(cplx);
+    const size_t a = (size_t)Geo<H>::TC * (H + Geo<H>::SKEW) * sizeof(double), b = (size_t)H * sizeof(cplx);
     return a > b ? a : b;
 }
 template <typename K> hipError_t raise_lds(K kernel, size_t lds) {

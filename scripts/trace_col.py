@@ -48,3 +48,7 @@ if t[0, 7, 0] != 0:
     print("packed column 0 (wg 0): lds in %.1f | iterations " % ((t[0, 7, 1] - t[0, 7, 0]) / 100)
           + " ".join("%.1f" % ((t[0, 7, k] - t[0, 7, k - 1]) / 100) for k in range(2, 7) if t[0, 7, k] != 0)
           + " | total %.1f us" % ((t[0, 7, 7] - t[0, 7, 0]) / 100))
+if t[:, 6, 0].any():
+    d = np.diff(t[:nwg, 6, :6], axis=1) / 100.0
+    print("forward column FFT of the last tile, mean over workgroups (us): "
+          + "  ".join(f"{nm} {np.mean(d[:, k]):.2f}" for k, nm in enumerate(["stage1", "exchange1", "stage2", "exchange2", "stage3"])))
