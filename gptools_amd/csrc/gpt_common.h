@@ -213,6 +213,11 @@ struct EwPtrs {
     double* out;
     double* out_cov;
     cplx* out_c;
+    // Optional staging of the two edge columns (j = 0 and W/2), contiguous per lattice: edge_cov[0..H) =
+    // cov[:, 0], [H..2H) = cov[:, W/2] (filled by an earlier pass); edge_dcov the same for d/dcov (scattered
+    // into out_cov by a later pass). Null: the elementwise stage reads cov / writes out_cov itself.
+    const double* edge_cov;
+    double* edge_dcov;
 };
 
 __device__ __forceinline__ EwPtrs make_ptrs(const LatArgs& a, int64_t b) {
@@ -225,6 +230,8 @@ __device__ __forceinline__ EwPtrs make_ptrs(const LatArgs& a, int64_t b) {
     P.out = a.out ? a.out + b * hw : nullptr;
     P.out_cov = a.out_cov ? a.out_cov + b * hwf : nullptr;
     P.out_c = a.out_c ? a.out_c + b * hwf : nullptr;
+    P.edge_cov = nullptr;
+    P.edge_dcov = nullptr;
     return P;
 }
 
@@ -351,7 +358,10 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
             const double q = FA.x * FA.x * inv_c / n;
             acc.sum -= 0.5 * (q + log(c));
             if (op_is_lpdf_vjp(OP)) {
-                if (OP == OP_LPDF_VJP) P.out_cov[ck] = 0.5 * (q - 1.0) * inv_c;
+                if (OP == OP_LPDF_VJP) {
+                    if (P.edge_dcov) P.edge_dcov[(j ? a.H : 0) + k] = 0.5 * (q - 1.0) * inv_c;
+                    else P.out_cov[ck] = 0.5 * (q - 1.0) * inv_c;
+                }
                 ret = make_double2(FA.x * inv_c, 0.0);
             }
         } else {
@@ -359,8 +369,13 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
             acc.sum -= q + log(c);
             if (op_is_lpdf_vjp(OP)) {
                 if (OP == OP_LPDF_VJP) {
-                    P.out_cov[ck] = (q - 1.0) * inv_c;
-                    P.out_cov[cm_] = 0.0;
+                    if (P.edge_dcov) {
+                        P.edge_dcov[(j ? a.H : 0) + k] = (q - 1.0) * inv_c;
+                        P.edge_dcov[(j ? a.H : 0) + km] = 0.0;
+                    } else {
+                        P.out_cov[ck] = (q - 1.0) * inv_c;
+                        P.out_cov[cm_] = 0.0;
+                    }
                 }
                 ret = cscale(FA, inv_c);
             }
@@ -420,6 +435,16 @@ __device__ __forceinline__ EdgeCov load_edge_cov(const LatArgs& a, const ZLayout
     EdgeCov e = {1.0, 1.0, 1.0, 1.0};
     if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
         const bool real_pt = (k == 0) || (2 * k == a.H);
+        if (P.edge_cov) {
+            const int km = real_pt ? k : a.H - k;
+            e.c0 = P.edge_cov[k];
+            e.c0m = P.edge_cov[km];
+            if ((a.W % 2) == 0) {
+                e.ch = P.edge_cov[a.H + k];
+                e.chm = P.edge_cov[a.H + km];
+            }
+            return e;
+        }
         const unsigned rk = (unsigned)k * (unsigned)L.Wf, rm = (unsigned)(real_pt ? k : a.H - k) * (unsigned)L.Wf;
         e.c0 = P.cov[rk];
         e.c0m = P.cov[rm];

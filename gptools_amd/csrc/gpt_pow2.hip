@@ -19,7 +19,12 @@ template <typename F> hipError_t by_size(int n, F f) {
 
 bool gpt_pow2_supported(int H, int W) { return is_pow2_in_range(H) && is_pow2_in_range(W); }
 
-size_t gpt_pow2_workspace_bytes(int H, int W) { return (size_t)H * (size_t)(W / 2 + GPT_WS_PAD) * sizeof(cplx); }
+// per lattice: the packed spectrum, then 4 H doubles of edge-column staging (cov[:,0], cov[:,W/2] and the
+// same two columns of d/dcov)
+static size_t ws_spec_elems(int H, int W) { return (size_t)H * (size_t)(W / 2 + GPT_WS_PAD); }
+size_t gpt_pow2_workspace_bytes(int H, int W) {
+    return ws_spec_elems(H, W) * sizeof(cplx) + 4 * (size_t)H * sizeof(double);
+}
 
 int gpt_pow2_col_blocks(int H, int W, int cus) {
     int nb = 1;
@@ -39,13 +44,17 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
     const bool reduces = (op != OP_RFFT2 && op != OP_INV_RFFT2);
     const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op));
     const double add = -0.5 * n * 1.8378770664093454836;
+    // edge-column staging (speed only): cov by pass A when the op has one and reads cov; d/dcov through pass C
+    // for the fused log-density gradient
+    double* edge = reinterpret_cast<double*>(ws + (size_t)a.batch * ws_spec_elems(a.H, a.W));
+    const int edge_flags = ((op_has_fwd(op) && a.cov) ? 1 : 0) | ((op == OP_LPDF_VJP && a.out_cov) ? 2 : 0);
     if (pass == 0) {
         if (!op_has_fwd(op)) return hipSuccess;
         const int in_mode = op == OP_RFFT2 ? 0 : (op == OP_INV_VJP ? 2 : 1);
-        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, in_mode, ws, wstride, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, in_mode, ws, wstride, (edge_flags & 1) ? edge : nullptr, st); });
     }
     if (pass == 1) {
-        hipError_t e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, ws, wstride, partials, nblk, st); });
+        hipError_t e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, ws, wstride, partials, nblk, edge_flags ? edge : nullptr, edge_flags, st); });
         if (e != hipSuccess) return e;
         // second reduction stage: folded into pass C when there is one
         if (reduces && !op_has_inv(op))
@@ -67,7 +76,7 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
         if (op == OP_INV_RFFT2) alpha = 1.0 / n;
         else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
         else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
-        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, fin, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, st); });
     }
     return hipErrorInvalidValue;
 }

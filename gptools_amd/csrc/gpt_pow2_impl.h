@@ -364,7 +364,7 @@ template <int N> struct Geo {
 // in_mode: 0 = x, 1 = x - loc, 2 = aux
 template <int W>
 __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a, int in_mode, cplx* __restrict__ ws,
-                                                                      int wstride) {
+                                                                      int wstride, double* __restrict__ edge) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int T = Geo<W>::T, LINES = Geo<W>::ROW_LINES;
     const int line = threadIdx.x / T, t = threadIdx.x - line * T;
@@ -415,6 +415,16 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
         zc[m].y = lds[phys(j == 0 ? 0 : W - j)];
     }
     if (!active) return;
+    if (edge && a.cov && t == 0) {
+        // stage the two edge columns of cov contiguously for the column pass (its packed column 0 would
+        // otherwise gather them, 64 lines per load instruction, while everybody else streams)
+        const double* cv = a.cov + b * a.cov_bs + (int64_t)(2 * rr) * (W / 2 + 1);
+        double* e = edge + b * 4 * (int64_t)H + 2 * rr;
+        e[0] = cv[0];
+        e[1] = cv[W / 2 + 1];
+        e[H] = cv[W / 2];
+        e[H + 1] = cv[W / 2 + 1 + W / 2];
+    }
     cplx* s0 = ws + ((int64_t)b * H + 2 * rr) * wstride;
     cplx* s1 = s0 + wstride;
 #pragma unroll
@@ -437,7 +447,7 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
 template <int W>
 __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a, double alpha, int add_loc,
                                                                       const cplx* __restrict__ ws, int wstride,
-                                                                      FinArgs fin) {
+                                                                      FinArgs fin, const double* __restrict__ edge) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int T = Geo<W>::T, LINES = Geo<W>::ROW_LINES;
     const int line = threadIdx.x / T, t = threadIdx.x - line * T;
@@ -477,6 +487,15 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
         finalize_block(fin, b, reinterpret_cast<double*>(smem));
     }
     if (!active) return;
+    if (edge && a.out_cov && t == 0) {
+        // the column pass left d/dcov of the two edge columns contiguous: put rows 2rr, 2rr+1 in place
+        const double* e = edge + b * 4 * (int64_t)H + 2 * (int64_t)H + 2 * rr;
+        double* oc = a.out_cov + b * (int64_t)H * (W / 2 + 1) + (int64_t)(2 * rr) * (W / 2 + 1);
+        oc[0] = e[0];
+        oc[W / 2 + 1] = e[1];
+        oc[W / 2] = e[H];
+        oc[W / 2 + 1 + W / 2] = e[H + 1];
+    }
     double* o0 = a.out + b * (int64_t)H * W + (int64_t)(2 * rr) * W;
     double* o1 = o0 + W;
     if (add_loc && a.loc) {
@@ -507,7 +526,8 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
 // register tile k of the thread sits at line position t[k] = tp + k*TP, i.e. rows t[k] + T*m.
 template <int H, int OP>
 __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, cplx* __restrict__ ws, int wstride,
-                                                                     double* __restrict__ partials, int ntiles) {
+                                                                     double* __restrict__ partials, int ntiles,
+                                                                     double* __restrict__ edge, int edge_flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int T = Geo<H>::T, TC = Geo<H>::TC, V = Geo<H>::V, TP = Geo<H>::TP;
     constexpr int NPRE = tw_npre<H>();
@@ -520,7 +540,11 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
     double* red = reinterpret_cast<double*>(smem); // reused after the FFTs are done with LDS
     const int64_t b = blockIdx.y;
     const ZLayout L = make_layout(a);
-    const EwPtrs P = make_ptrs(a, b);
+    EwPtrs P = make_ptrs(a, b);
+    if (edge) { // edge_flags: 1 = cov staged by pass A, 2 = d/dcov to be scattered by pass C
+        if (edge_flags & 1) P.edge_cov = edge + b * 4 * (int64_t)H;
+        if (edge_flags & 2) P.edge_dcov = edge + b * 4 * (int64_t)H + 2 * (int64_t)H;
+    }
     cplx* wsb = ws + (int64_t)b * H * wstride; // uniform base; 32-bit element offsets below
     cplx wpre[V][NPRE];
 #pragma unroll
@@ -689,10 +713,11 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
 }
 
 template <int N> struct Launch {
-    static hipError_t row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, hipStream_t st);
+    static hipError_t row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, hipStream_t st);
     static hipError_t row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
-                              const FinArgs& fin, hipStream_t st);
-    static hipError_t col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg, hipStream_t st);
+                              const FinArgs& fin, const double* edge, hipStream_t st);
+    static hipError_t col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg, double* edge,
+                          int edge_flags, hipStream_t st);
     // grid of the persistent column kernel = number of per-lattice partials, one workgroup per CU it may use
     static int col_blocks(int W, int cus) {
         const int ntiles = (W / 2) / Geo<N>::TC;

@@ -21,32 +21,35 @@ template <typename K> hipError_t raise_lds(K kernel, size_t lds) {
 } // namespace
 
 template <>
-hipError_t Launch<GPT_N>::row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, hipStream_t st) {
+hipError_t Launch<GPT_N>::row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge,
+                                  hipStream_t st) {
     constexpr int W = GPT_N;
     const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(double);
     hipError_t e = raise_lds(row_fwd_kernel<W>, lds);
     if (e != hipSuccess) return e;
     const int npairs = a.H / 2;
     dim3 grid((npairs + Geo<W>::ROW_LINES - 1) / Geo<W>::ROW_LINES, (unsigned)a.batch);
-    hipLaunchKernelGGL(row_fwd_kernel<W>, grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, in_mode, ws, wstride);
+    hipLaunchKernelGGL(row_fwd_kernel<W>, grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, in_mode, ws, wstride, edge);
     return hipGetLastError();
 }
 
 template <>
 hipError_t Launch<GPT_N>::row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
-                                  const FinArgs& fin, hipStream_t st) {
+                                  const FinArgs& fin, const double* edge, hipStream_t st) {
     constexpr int W = GPT_N;
     const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(double);
     hipError_t e = raise_lds(row_inv_kernel<W>, lds);
     if (e != hipSuccess) return e;
     const int npairs = a.H / 2;
     dim3 grid((npairs + Geo<W>::ROW_LINES - 1) / Geo<W>::ROW_LINES, (unsigned)a.batch);
-    hipLaunchKernelGGL(row_inv_kernel<W>, grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, alpha, add_loc, ws, wstride, fin);
+    hipLaunchKernelGGL(row_inv_kernel<W>, grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, alpha, add_loc, ws, wstride, fin,
+                       edge);
     return hipGetLastError();
 }
 
 template <int OP>
-static hipError_t col_t(const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg, hipStream_t st) {
+static hipError_t col_t(const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg, double* edge,
+                        int edge_flags, hipStream_t st) {
     constexpr int H = GPT_N;
     const size_t lds = col_lds_bytes<H>();
     hipError_t e = raise_lds(col_kernel<H, OP>, lds);
@@ -54,23 +57,23 @@ static hipError_t col_t(const LatArgs& a, cplx* ws, int wstride, double* partial
     const int ntiles = (a.W / 2) / Geo<H>::TC;
     dim3 grid((unsigned)nwg, (unsigned)a.batch);
     hipLaunchKernelGGL((col_kernel<H, OP>), grid, dim3(Geo<H>::COL_THREADS), lds, st, a, ws, wstride, partials,
-                       ntiles);
+                       ntiles, edge, edge_flags);
     return hipGetLastError();
 }
 
 template <>
 hipError_t Launch<GPT_N>::col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg,
-                              hipStream_t st) {
+                              double* edge, int edge_flags, hipStream_t st) {
     switch (op) {
-    case OP_RFFT2: return col_t<OP_RFFT2>(a, ws, wstride, partials, nwg, st);
-    case OP_INV_RFFT2: return col_t<OP_INV_RFFT2>(a, ws, wstride, partials, nwg, st);
-    case OP_GP_RFFT2: return col_t<OP_GP_RFFT2>(a, ws, wstride, partials, nwg, st);
-    case OP_GP_INV_RFFT2: return col_t<OP_GP_INV_RFFT2>(a, ws, wstride, partials, nwg, st);
-    case OP_LPDF: return col_t<OP_LPDF>(a, ws, wstride, partials, nwg, st);
-    case OP_LPDF_VJP: return col_t<OP_LPDF_VJP>(a, ws, wstride, partials, nwg, st);
-    case OP_INV_VJP: return col_t<OP_INV_VJP>(a, ws, wstride, partials, nwg, st);
-    case OP_FWD_VJP: return col_t<OP_FWD_VJP>(a, ws, wstride, partials, nwg, st);
-    case OP_LPDF_VJP_NOCOV: return col_t<OP_LPDF_VJP_NOCOV>(a, ws, wstride, partials, nwg, st);
+    case OP_RFFT2: return col_t<OP_RFFT2>(a, ws, wstride, partials, nwg, edge, edge_flags, st);
+    case OP_INV_RFFT2: return col_t<OP_INV_RFFT2>(a, ws, wstride, partials, nwg, edge, edge_flags, st);
+    case OP_GP_RFFT2: return col_t<OP_GP_RFFT2>(a, ws, wstride, partials, nwg, edge, edge_flags, st);
+    case OP_GP_INV_RFFT2: return col_t<OP_GP_INV_RFFT2>(a, ws, wstride, partials, nwg, edge, edge_flags, st);
+    case OP_LPDF: return col_t<OP_LPDF>(a, ws, wstride, partials, nwg, edge, edge_flags, st);
+    case OP_LPDF_VJP: return col_t<OP_LPDF_VJP>(a, ws, wstride, partials, nwg, edge, edge_flags, st);
+    case OP_INV_VJP: return col_t<OP_INV_VJP>(a, ws, wstride, partials, nwg, edge, edge_flags, st);
+    case OP_FWD_VJP: return col_t<OP_FWD_VJP>(a, ws, wstride, partials, nwg, edge, edge_flags, st);
+    case OP_LPDF_VJP_NOCOV: return col_t<OP_LPDF_VJP_NOCOV>(a, ws, wstride, partials, nwg, edge, edge_flags, st);
     default: return hipErrorInvalidValue;
     }
 }
