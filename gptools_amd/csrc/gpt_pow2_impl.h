@@ -604,14 +604,6 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
 #endif
         TRACE_MARK(r, 2); // ... and arrived
         const bool own0 = (j0 == 0); // workgroup-uniform: this tile holds the packed column 0
-        // its first cov values are requested before the transform: when the other workgroups are in their
-        // elementwise stage a load takes >10 us, and this workgroup is the one the kernel waits for
-        EdgeCov ec = {1.0, 1.0, 1.0, 1.0}, en = ec;
-        if (own0) {
-            const int k0 = threadIdx.x, k1 = k0 + Geo<H>::COL_THREADS;
-            ec = load_edge_cov<OP>(a, L, P, k0 <= H / 2 ? k0 : 0);
-            en = load_edge_cov<OP>(a, L, P, k1 <= H / 2 ? k1 : 0);
-        }
         if (op_has_fwd(OP)) fft_regs<H, false, V, Geo<H>::SWZ>(v, tl, lds, wl);
         TRACE_MARK(r, 3);
         if (own0) {
@@ -628,10 +620,11 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
             }
             __syncthreads();
             TRACE_MARK(7, 1);
+            EdgeCov ec = load_edge_cov<OP>(a, L, P, threadIdx.x <= H / 2 ? threadIdx.x : 0);
 #pragma unroll 1
             for (int kk = threadIdx.x; kk <= H / 2; kk += Geo<H>::COL_THREADS) {
-                const int kn = kk + 2 * Geo<H>::COL_THREADS;
-                const EdgeCov e2 = load_edge_cov<OP>(a, L, P, kn <= H / 2 ? kn : 0);
+                const int kn = kk + Geo<H>::COL_THREADS;
+                const EdgeCov en = load_edge_cov<OP>(a, L, P, kn <= H / 2 ? kn : 0);
                 const bool self = (kk == 0) || (kk == H / 2);
                 cplx Zk = lds0[phys(kk)];
                 cplx Zm = self ? Zk : lds0[phys(H - kk)];
@@ -641,7 +634,6 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
                     if (!self) lds0[phys(H - kk)] = Zm;
                 }
                 ec = en;
-                en = e2;
                 TRACE_MARK(7, 2 + kk / Geo<H>::COL_THREADS);
             }
             __syncthreads();
