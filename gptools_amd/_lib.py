@@ -56,6 +56,9 @@ _SIGNATURES = {
     "gpt_gp_periodic_matern_cov_rfft2_host": [c_int, c_dbl, c_i64, c_i64, c_ptr, c_int, c_ptr],
     "gpt_gp_periodic_exp_quad_cov_rfft2_vjp_host": [c_int, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr],
     "gpt_gp_periodic_matern_cov_rfft2_vjp_host": [c_int, c_dbl, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr],
+    "gpt_slab_rows_fwd": [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64],
+    "gpt_slab_cols_lpdf_vjp": [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr],
+    "gpt_slab_rows_inv": [c_ptr, c_i64, c_i64, c_i64, c_i64, c_dbl, c_ptr],
 }
 # entry points without the leading context argument / with other return types
 _PLAIN = {

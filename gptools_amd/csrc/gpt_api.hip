@@ -352,6 +352,90 @@ const char* gpt_last_error(const gpt_ctx* c) { return c ? c->err.c_str() : "null
 double gpt_last_min_eig(const gpt_ctx* c) { return c ? c->last_min_eig : NAN; }
 int gpt_path_for_shape(int64_t H, int64_t W) { return path_for_shape(H, W); }
 
+// ---- slab decomposition: one lattice over several GPUs ----------------------------------------------
+// (no counterpart in the reference, which is single-process: SURVEY 8(e)). Each rank owns `rows` consecutive
+// rows of y / loc / d/dy and `ncols` consecutive packed columns of the half spectrum; the exchange between
+// the two layouts is the caller's (gptools_amd/slab.py: all-to-all over RCCL).
+static int slab_check(gpt_ctx* c, int64_t H, int64_t W) {
+    if (!c) return GPT_ERR_SHAPE;
+    if (!gpt_pow2_supported((int)H, (int)W))
+        return fail(c, GPT_ERR_UNSUPPORTED, "slab passes need power-of-two axes between 256 and 8192");
+    return GPT_OK;
+}
+static int slab_cus(gpt_ctx* c) {
+    if (c->total_cus == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return 256;
+        c->total_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return c->total_cus;
+}
+
+int gpt_slab_rows_fwd(gpt_ctx* c, const double* y, const double* loc, int64_t rows, int64_t H, int64_t W,
+                      double* spec, int64_t ld) {
+    int rc = slab_check(c, H, W);
+    if (rc) return rc;
+    if (rows < 2 || rows % 2 || rows > H || ld < W / 2 || !y || !spec)
+        return fail(c, GPT_ERR_SHAPE, "rows must be even, 2 <= rows <= height, and ld >= width / 2");
+    HIP_TRY(c, hipSetDevice(c->device));
+    LatArgs a = base_args(rows, W, 1, 0);
+    if ((rc = make_plan(c, a.W, a.pw)) != GPT_OK) return rc;
+    a.x = y;
+    a.loc = loc;
+    HIP_TRY(c, gpt_pow2_slab_pass(0, OP_LPDF_VJP, a, reinterpret_cast<cplx*>(spec), (int)ld, 1.0, nullptr,
+                                  slab_cus(c), c->stream));
+    return GPT_OK;
+}
+
+int gpt_slab_cols_lpdf_vjp(gpt_ctx* c, double* spec, int64_t ld, const double* cov, double* out_cov, int64_t H,
+                           int64_t W, int64_t col0, int64_t ncols, double* lpdf_partial, double* min_partial) {
+    int rc = slab_check(c, H, W);
+    if (rc) return rc;
+    const int tile = gpt_pow2_col_tile((int)H);
+    if (col0 < 0 || ncols < 1 || col0 + ncols > W / 2 || ncols % tile || col0 % tile || ld < ncols || !spec || !cov ||
+        !lpdf_partial) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "column slab [%lld, %lld) must lie in [0, width/2) and be aligned to %d columns",
+                 (long long)col0, (long long)(col0 + ncols), tile);
+        return fail(c, GPT_ERR_SHAPE, buf);
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    LatArgs a = base_args(H, W, 1, 0);
+    if ((rc = make_plan(c, a.H, a.ph)) != GPT_OK) return rc;
+    a.cov = cov;
+    a.out_cov = out_cov;
+    a.col0 = (int)col0;
+    a.ncols = (int)ncols;
+    a.out_lpdf = lpdf_partial;
+    a.min_eig = min_partial;
+    const int cus = slab_cus(c);
+    const int nblk = gpt_pow2_col_blocks(a.H, 2 * a.ncols, cus);
+    if ((rc = ensure(c, c->partials, c->partials_bytes, sizeof(double) * GPT_PART * (size_t)nblk)) != GPT_OK) return rc;
+    if (!out_cov) {
+        const size_t need = sizeof(double) * (size_t)H * (size_t)(W / 2 + 1);
+        if ((rc = ensure(c, c->sink, c->sink_bytes, need)) != GPT_OK) return rc;
+        a.out_cov = c->sink;
+    }
+    HIP_TRY(c, gpt_pow2_slab_pass(1, OP_LPDF_VJP, a, reinterpret_cast<cplx*>(spec), (int)ld, 1.0, c->partials, cus,
+                                  c->stream));
+    return GPT_OK;
+}
+
+int gpt_slab_rows_inv(gpt_ctx* c, const double* spec, int64_t ld, int64_t rows, int64_t H, int64_t W, double alpha,
+                      double* out) {
+    int rc = slab_check(c, H, W);
+    if (rc) return rc;
+    if (rows < 2 || rows % 2 || rows > H || ld < W / 2 || !out || !spec)
+        return fail(c, GPT_ERR_SHAPE, "rows must be even, 2 <= rows <= height, and ld >= width / 2");
+    HIP_TRY(c, hipSetDevice(c->device));
+    LatArgs a = base_args(rows, W, 1, 0);
+    if ((rc = make_plan(c, a.W, a.pw)) != GPT_OK) return rc;
+    a.out = out;
+    HIP_TRY(c, gpt_pow2_slab_pass(2, OP_LPDF_VJP, a, const_cast<cplx*>(reinterpret_cast<const cplx*>(spec)), (int)ld,
+                                  alpha, nullptr, slab_cus(c), c->stream));
+    return GPT_OK;
+}
+
 // ---- real-FFT layer --------------------------------------------------------------------------------
 int gpt_rfft2(gpt_ctx* c, const double* y, int64_t H, int64_t W, int64_t batch, double* out_complex) {
     int rc = check_shape(c, H, W, batch, 0);

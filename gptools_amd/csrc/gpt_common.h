@@ -69,6 +69,10 @@ struct LatArgs {
     double* out_lpdf; // [batch]
     double* min_eig;  // [batch]: min over the whole H x Wf matrix of n*c/2 (may be null)
     LinePlan pw, ph;  // line plans for length W and length H
+    // Column slab (one lattice split over several GPUs, gpt_slab_*): the column pass works on packed columns
+    // col0 .. col0 + ncols - 1 of the lattice; the spectrum buffer holds just those, cov / out_cov keep the
+    // lattice's own H x Wf layout. ncols == 0: the whole lattice.
+    int col0, ncols;
 };
 
 // ---------------------------------------------------------------------------------------------------

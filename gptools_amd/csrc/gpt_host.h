@@ -19,6 +19,11 @@ int gpt_pow2_col_blocks(int H, int W, int cus);
 // must be the same for the three passes of one lattice.
 hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* partials, int col_cus,
                          hipStream_t st);
+// Slab decomposition (gpt_pow2.hip): column-tile width for lines of length H and the three passes on
+// caller-owned spectrum buffers.
+int gpt_pow2_col_tile(int H);
+hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, int ld, double alpha, double* partials,
+                              int cus, hipStream_t st);
 
 // --- generic large path (gpt_generic.hip): any H, W whose lines fit LDS
 bool gpt_generic_supported(int H, int W);

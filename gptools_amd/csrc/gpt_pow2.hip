@@ -80,3 +80,35 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
     }
     return hipErrorInvalidValue;
 }
+
+// Columns a column-pass workgroup takes at once for lines of length H: slab widths must be multiples of it.
+int gpt_pow2_col_tile(int H) {
+    int tc = 0;
+    (void)by_size(H, [&](auto l) {
+        tc = decltype(l)::col_tile();
+        return hipSuccess;
+    });
+    return tc;
+}
+
+// The three passes on caller-owned spectrum buffers (slab decomposition of one lattice over several GPUs).
+//   pass 0: rows -> packed half spectrum of `a.H` (= local rows, even) rows of width a.W; spec[rows][ld]
+//   pass 1: column pass of `op` on packed columns a.col0 .. a.col0 + a.ncols - 1, all a.H rows; spec[H][ld];
+//           the per-workgroup partials are summed into a.out_lpdf[0] (no constant added) and a.min_eig[0]
+//   pass 2: spec[rows][ld] -> a.out[rows][W] = alpha * (inverse row transform)
+hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, int ld, double alpha, double* partials,
+                              int cus, hipStream_t st) {
+    if (pass == 0)
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, a.loc ? 1 : 0, spec, ld, nullptr, st); });
+    if (pass == 1) {
+        const int nblk = gpt_pow2_col_blocks(a.H, 2 * a.ncols, cus); // tiles = ncols / tile width
+        hipError_t e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, spec, ld, partials, nblk, nullptr, 0, st); });
+        if (e != hipSuccess) return e;
+        return gpt_launch_finalize(partials, nblk, 1, 1, 0.0, a.out_lpdf, a.min_eig, st);
+    }
+    if (pass == 2) {
+        const FinArgs fin = {nullptr, 0, 0.0, nullptr, nullptr};
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, 0, spec, ld, fin, nullptr, st); });
+    }
+    return hipErrorInvalidValue;
+}

@@ -570,7 +570,8 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
     for (int r = 0; r < count; ++r) {
         const int tile = first + r * step;
         const int j0 = tile * TC;
-        const int jp = j0 + c; // packed column
+        const int jl = j0 + c;      // packed column inside the spectrum buffer
+        const int jp = a.col0 + jl; // ... and inside the lattice (cov, d/dcov, z layouts)
         // The thread's line positions, laundered through an empty asm: every address below then depends on a
         // per-iteration opaque value, which keeps loop-invariant code motion from hoisting ~100 address
         // registers out of the tile loop (they are cheap to recompute and expensive to keep) ...
@@ -596,14 +597,14 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
         for (int k = 0; k < V; ++k)
 #pragma unroll
             for (int m = 0; m < E; ++m)
-                v[k][m] = op_has_fwd(OP) ? wsb[(unsigned)(tl[k] + T * m) * (unsigned)wstride + (unsigned)jp]
+                v[k][m] = op_has_fwd(OP) ? wsb[(unsigned)(tl[k] + T * m) * (unsigned)wstride + (unsigned)jl]
                                          : make_double2(0.0, 0.0);
 #if GPT_TRACE
         TRACE_MARK(r, 1); // loads issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         TRACE_MARK(r, 2); // ... and arrived
-        const bool own0 = (j0 == 0); // workgroup-uniform: this tile holds the packed column 0
+        const bool own0 = (a.col0 + j0 == 0); // workgroup-uniform: this tile holds the packed column 0
         if (op_has_fwd(OP)) fft_regs<H, false, V, Geo<H>::SWZ>(v, tl, lds, wl);
         TRACE_MARK(r, 3);
         if (own0) {
@@ -688,7 +689,7 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
             for (int k = 0; k < V; ++k)
 #pragma unroll
                 for (int m = 0; m < E; ++m)
-                    wsb[(unsigned)(t_inv[k] + T * m) * (unsigned)wstride + (unsigned)jp] = v[k][m];
+                    wsb[(unsigned)(t_inv[k] + T * m) * (unsigned)wstride + (unsigned)jl] = v[k][m];
             TRACE_MARK(r, 7);
         }
     }
@@ -711,6 +712,7 @@ template <int N> struct Launch {
     static hipError_t col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg, double* edge,
                           int edge_flags, hipStream_t st);
     // grid of the persistent column kernel = number of per-lattice partials, one workgroup per CU it may use
+    static int col_tile() { return Geo<N>::TC; }
     static int col_blocks(int W, int cus) {
         const int ntiles = (W / 2) / Geo<N>::TC;
         int cap = cus * GPT_COL_WGS_PER_CU;

@@ -54,7 +54,7 @@ static hipError_t col_t(const LatArgs& a, cplx* ws, int wstride, double* partial
     const size_t lds = col_lds_bytes<H>();
     hipError_t e = raise_lds(col_kernel<H, OP>, lds);
     if (e != hipSuccess) return e;
-    const int ntiles = (a.W / 2) / Geo<H>::TC;
+    const int ntiles = (a.ncols > 0 ? a.ncols : a.W / 2) / Geo<H>::TC;
     dim3 grid((unsigned)nwg, (unsigned)a.batch);
     hipLaunchKernelGGL((col_kernel<H, OP>), grid, dim3(Geo<H>::COL_THREADS), lds, st, a, ws, wstride, partials,
                        ntiles, edge, edge_flags);

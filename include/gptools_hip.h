@@ -72,6 +72,29 @@ int gpt_profile_end(gpt_ctx* ctx, double* pass_ms, int64_t* launches);
  * 1 power-of-two three-pass, 2 generic three-pass, -1 unsupported. */
 int gpt_path_for_shape(int64_t height, int64_t width);
 
+/* ---- slab decomposition: ONE lattice over several GPUs (no counterpart in the reference, which
+ * is single-process) ---------------------------------------------------------------------------------
+ * Rank g owns `rows` consecutive rows of y, loc and d/dy (row slab) and `ncols` consecutive PACKED columns of
+ * the half spectrum (column slab; packed column j holds frequency j, column 0 holds DC + i * Nyquist). The
+ * exchange between the two layouts (an all-to-all over RCCL) belongs to the caller: gptools_amd/slab.py.
+ * Device pointers, asynchronous on the context's stream, power-of-two height and width in [256, 8192].
+ *   gpt_slab_rows_fwd:      spec[rows][ld] complex <- packed real FFT along the width of (y - loc)[rows][W]
+ *   gpt_slab_cols_lpdf_vjp: on spec[H][ld] (all rows of columns col0 .. col0+ncols-1), in place: column FFT,
+ *                           log-density terms of fft2.stan:189-192 and F/c, inverse column FFT. cov and
+ *                           out_cov (may be NULL) are whole H x (W/2+1) arrays of which only the slab's
+ *                           columns (and column W/2 on the rank that owns packed column 0) are touched.
+ *                           lpdf_partial[0] <- this slab's sum WITHOUT the -(n/2) log(2 pi) constant,
+ *                           min_partial[0] (may be NULL) <- min of n*c/2 over the slab. col0 and ncols must be
+ *                           multiples of the column tile (4 at H = 4096).
+ *   gpt_slab_rows_inv:      out[rows][W] <- alpha * inverse packed real FFT of spec[rows][ld]
+ *                           (alpha = -1/(H*W) gives d lpdf / d y). */
+int gpt_slab_rows_fwd(gpt_ctx*, const double* y, const double* loc, int64_t rows, int64_t height, int64_t width,
+                      double* spec, int64_t ld);
+int gpt_slab_cols_lpdf_vjp(gpt_ctx*, double* spec, int64_t ld, const double* cov, double* out_cov, int64_t height,
+                           int64_t width, int64_t col0, int64_t ncols, double* lpdf_partial, double* min_partial);
+int gpt_slab_rows_inv(gpt_ctx*, const double* spec, int64_t ld, int64_t rows, int64_t height, int64_t width,
+                      double alpha, double* out);
+
 /* ---- real-FFT layer: stan/gptools/util.stan:255-330 ------------------------------------------------ */
 /* rfft2 (util.stan:302-304): y[batch][H][W] -> out[batch][H][W/2+1] complex.  rfft (util.stan:263-265) is
  * the height == 1 case. */

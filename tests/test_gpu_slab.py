@@ -1,0 +1,111 @@
+"""
+Slab decomposition on the GPU: the protocol of gptools_amd.slab with the HIP passes, G ranks
+simulated by G threads on the one device of the test box (ThreadComm), against the oracle and against the
+single-GPU entry point. The multi-process exchange itself is covered on CPU by test_slab_gloo.py.
+"""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10  # north-star tolerance
+
+
+def _run_slab(y, loc, cov, world):
+    from gptools_amd import slab
+
+    h, w = y.shape
+    rows, nc = slab.slab_shapes(h, w, world)
+    dev = torch.device("cuda", 0)
+    cov_d = torch.from_numpy(cov).to(dev)
+    shared = slab.ThreadComm.Shared(world)
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(dev)
+            sl = slice(rank * rows, (rank + 1) * rows)
+            out_cov = torch.full((h, w // 2 + 1), float("nan"), dtype=torch.float64, device=dev)
+            lp, gy, mn = slab.gp_rfft2_lpdf_vjp_slab(torch.from_numpy(y[sl].copy()).to(dev),
+                                                     torch.from_numpy(loc[sl].copy()).to(dev), cov_d, h, w,
+                                                     comm=slab.ThreadComm(shared, rank), out_cov=out_cov)
+            torch.cuda.synchronize()
+            results[rank] = (float(lp), gy.cpu().numpy(), float(mn), out_cov.cpu().numpy())
+        except Exception as exc:  # surface the failure instead of a hung barrier
+            errors.append(exc)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    if errors:
+        raise errors[0]
+    return results, rows, nc
+
+
+@pytest.mark.parametrize("h,w,world", [(512, 512, 1), (512, 512, 2), (512, 512, 4), (1024, 256, 4), (256, 512, 2),
+                                       (256, 1024, 8)])
+def test_slab_matches_oracle(h, w, world):
+    import gp_oracle as oracle
+
+    rng = np.random.default_rng(h + w + world)
+    cov = oracle.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.2, [6.0, 9.0], [float(h), float(w)]) + 1e-3
+    loc = rng.normal(size=(h, w))
+    y = loc + oracle.gp_inv_rfft2(rng.normal(size=(h, w)), np.zeros((h, w)), cov)
+    lp_ref, gy_ref, gc_ref = oracle.gp_rfft2_lpdf_vjp(y, loc, cov)
+    results, rows, nc = _run_slab(y, loc, cov, world)
+    gc = np.full_like(gc_ref, np.nan)
+    gscale = np.abs(gy_ref).max()
+    for rank, (lp, gy, mn, oc) in enumerate(results):
+        np.testing.assert_allclose(lp, lp_ref, rtol=RTOL)
+        np.testing.assert_allclose(gy, gy_ref[rank * rows:(rank + 1) * rows], rtol=RTOL, atol=RTOL * gscale)
+        np.testing.assert_allclose(mn, 0.5 * h * w * cov.min(), rtol=1e-13)
+        cols = list(range(rank * nc, (rank + 1) * nc)) + ([w // 2] if rank == 0 else [])
+        gc[:, cols] = oc[:, cols]
+    np.testing.assert_allclose(gc, gc_ref, rtol=RTOL, atol=RTOL * np.abs(gc_ref).max())
+
+
+def test_slab_headline_shape_eight_ranks():
+    """4096 x 4096 over 8 simulated ranks against the single-GPU fused entry point (same kernels, other split)."""
+    from gptools_amd import fft
+
+    h = w = 4096
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    cov = fft.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.3, [8.0, 12.0], [float(h), float(w)]) + 1e-3
+    loc = torch.randn(h, w, dtype=torch.float64, device=dev, generator=g)
+    y = fft.gp_inv_rfft2(torch.randn(h, w, dtype=torch.float64, device=dev, generator=g), loc, cov)
+    lp1, gy1, gc1 = fft.gp_rfft2_lpdf_vjp(y, loc, cov)
+    results, rows, nc = _run_slab(y.cpu().numpy(), loc.cpu().numpy(), cov.cpu().numpy(), 8)
+    gy1, gc1 = gy1.cpu().numpy(), gc1.cpu().numpy()
+    gscale = np.abs(gy1).max()
+    for rank, (lp, gy, mn, oc) in enumerate(results):
+        np.testing.assert_allclose(lp, float(lp1), rtol=RTOL)
+        np.testing.assert_allclose(gy, gy1[rank * rows:(rank + 1) * rows], rtol=RTOL, atol=RTOL * gscale)
+        cols = list(range(rank * nc, (rank + 1) * nc)) + ([w // 2] if rank == 0 else [])
+        np.testing.assert_allclose(oc[:, cols], gc1[:, cols], rtol=RTOL, atol=RTOL * np.abs(gc1).max())
+
+
+def test_slab_rejects_misaligned_columns():
+    from gptools_amd import fft
+
+    dev = torch.device("cuda", 0)
+    ctx = fft.get_context(dev)
+    spec = torch.zeros(4096, 6, dtype=torch.complex128, device=dev)
+    cov = torch.ones(4096, 2049, dtype=torch.float64, device=dev)
+    lp = torch.zeros(1, dtype=torch.float64, device=dev)
+    with pytest.raises(ValueError):  # 6 columns are not a multiple of the 4-column tile of H = 4096
+        ctx.call("gpt_slab_cols_lpdf_vjp", fft._p(spec), 6, fft._p(cov), None, 4096, 4096, 0, 6, fft._p(lp), None)
+    with pytest.raises(NotImplementedError):  # 32768-point lines are not built yet
+        ctx.call("gpt_slab_rows_fwd", fft._p(cov), None, 2, 32768, 32768, fft._p(spec), 16384)
