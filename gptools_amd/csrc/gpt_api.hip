@@ -359,7 +359,7 @@ int gpt_path_for_shape(int64_t H, int64_t W) { return path_for_shape(H, W); }
 static int slab_check(gpt_ctx* c, int64_t H, int64_t W) {
     if (!c) return GPT_ERR_SHAPE;
     if (!gpt_pow2_supported((int)H, (int)W))
-        return fail(c, GPT_ERR_UNSUPPORTED, "slab passes need power-of-two axes between 256 and 8192");
+        return fail(c, GPT_ERR_UNSUPPORTED, "slab passes need a power-of-two height in [256, 8192] and width in [256, 16384]");
     return GPT_OK;
 }
 static int slab_cus(gpt_ctx* c) {

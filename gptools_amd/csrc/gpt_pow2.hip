@@ -2,7 +2,7 @@
 #include "gpt_pow2_impl.h"
 
 namespace {
-bool is_pow2_in_range(int n) { return n >= 256 && n <= 8192 && (n & (n - 1)) == 0; }
+bool is_pow2_in_range(int n) { return n >= 256 && n <= 16384 && (n & (n - 1)) == 0; }
 
 template <typename F> hipError_t by_size(int n, F f) {
     switch (n) {
@@ -12,12 +12,15 @@ template <typename F> hipError_t by_size(int n, F f) {
     case 2048: return f(pow2::Launch<2048>());
     case 4096: return f(pow2::Launch<4096>());
     case 8192: return f(pow2::Launch<8192>());
+    case 16384: return f(pow2::Launch<16384>());
     default: return hipErrorInvalidValue;
     }
 }
 } // namespace
 
-bool gpt_pow2_supported(int H, int W) { return is_pow2_in_range(H) && is_pow2_in_range(W); }
+// Rows up to 16384 points (one line per 1024-thread workgroup). Columns up to 8192: the packed column 0 of
+// the column pass needs a whole complex column in LDS (H * 16 bytes).
+bool gpt_pow2_supported(int H, int W) { return is_pow2_in_range(H) && H <= 8192 && is_pow2_in_range(W); }
 
 // per lattice: the packed spectrum, then 4 H doubles of edge-column staging (cov[:,0], cov[:,W/2] and the
 // same two columns of d/dcov)

@@ -47,6 +47,7 @@ hipError_t Launch<GPT_N>::row_inv(const LatArgs& a, double alpha, int add_loc, c
     return hipGetLastError();
 }
 
+#if GPT_N <= 8192
 template <int OP>
 static hipError_t col_t(const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg, double* edge,
                         int edge_flags, hipStream_t st) {
@@ -77,6 +78,13 @@ hipError_t Launch<GPT_N>::col(int op, const LatArgs& a, cplx* ws, int wstride, d
     default: return hipErrorInvalidValue;
     }
 }
+#else
+// no column kernel for this line length (gpt_pow2_supported)
+template <>
+hipError_t Launch<GPT_N>::col(int, const LatArgs&, cplx*, int, double*, int, double*, int, hipStream_t) {
+    return hipErrorInvalidValue;
+}
+#endif
 
 } // namespace pow2
 
