@@ -46,6 +46,16 @@ def synthetic(fft, size, batch, device, seed):
     return y, loc, cov
 
 
+def pmc_traffic(size):
+    """Bytes per evaluation measured with rocprofv3 --pmc (scripts/pmc_passes.sh) and committed under profiles/."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            rec = json.load(fh)
+        return rec["per_eval_bytes"] if rec.get("shape") == [size, size] else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(size, budget_s=20.0):
     """Oracle (NumPy port of the reference maths, 1 core) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -246,7 +256,9 @@ def main():
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK,
-                "traffic": None,
+                "traffic": pmc_traffic(size),
+                "traffic_note": "HBM-side bytes per evaluation from committed rocprofv3 PMC passes "
+                                "(profiles/pmc_traffic.json), not collected in this run",
                 "kernel": "row_fwd + col + row_inv (three-pass pipeline of one evaluation)",
                 "algorithmic_bytes_per_eval": b_alg,
                 "device_s_per_eval": pipeline_s,
