@@ -158,8 +158,14 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # rehearsal on a one-GPU box: GPT_BENCH_REHEARSAL=1 puts every rank on device 0 and uses gloo
+        if os.environ.get("GPT_BENCH_REHEARSAL"):
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())

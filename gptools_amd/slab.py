@@ -66,6 +66,12 @@ class DistComm:
 
     def all_to_all(self, send):  # send[p] goes to rank p; returns recv with recv[p] from rank p
         real = torch.view_as_real(send.contiguous())
+        if real.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # rehearsals on a box without RCCL peers: gloo exchanges host tensors only
+            host = real.cpu()
+            out = torch.empty_like(host)
+            self.dist.all_to_all_single(out, host, group=self.group)
+            return torch.view_as_complex(out.to(real.device))
         out = torch.empty_like(real)
         self.dist.all_to_all_single(out, real, group=self.group)
         return torch.view_as_complex(out)

@@ -109,3 +109,66 @@ def test_slab_rejects_misaligned_columns():
         ctx.call("gpt_slab_cols_lpdf_vjp", fft._p(spec), 6, fft._p(cov), None, 4096, 4096, 0, 6, fft._p(lp), None)
     with pytest.raises(NotImplementedError):  # 32768-point lines are not built yet
         ctx.call("gpt_slab_rows_fwd", fft._p(cov), None, 2, 32768, 32768, fft._p(spec), 16384)
+
+
+def _dist_worker(rank, world, port, h, w, q):
+    import torch.distributed as dist
+
+    from gptools_amd import slab
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)  # the test box has one GPU: both ranks share it, gloo carries the exchange
+        torch.cuda.set_device(dev)
+        y, loc, cov = _dist_inputs(h, w)
+        rows = h // world
+        sl = slice(rank * rows, (rank + 1) * rows)
+        out_cov = torch.zeros(h, w // 2 + 1, dtype=torch.float64, device=dev)
+        lp, gy, mn = slab.gp_rfft2_lpdf_vjp_slab(torch.from_numpy(y[sl].copy()).to(dev),
+                                                 torch.from_numpy(loc[sl].copy()).to(dev),
+                                                 torch.from_numpy(cov).to(dev), h, w, comm=slab.DistComm(),
+                                                 out_cov=out_cov)
+        torch.cuda.synchronize()
+        dist.barrier()
+        q.put((rank, float(lp), gy.cpu().numpy(), float(mn)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _dist_inputs(h, w):
+    import gp_oracle as oracle
+
+    rng = np.random.default_rng(77)
+    cov = oracle.gp_periodic_exp_quad_cov_rfft2(h, w, 1.1, [5.0, 7.0], [float(h), float(w)]) + 1e-3
+    return rng.normal(size=(h, w)), rng.normal(size=(h, w)), cov
+
+
+def test_slab_two_processes_through_torch_distributed():
+    """The per-rank entry point under a real process group (two processes, gloo, one shared GPU)."""
+    import socket
+
+    import gp_oracle as oracle
+    import torch.multiprocessing as mp
+
+    h, w, world = 512, 256, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, h, w, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=240) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    y, loc, cov = _dist_inputs(h, w)
+    lp_ref, gy_ref, _ = oracle.gp_rfft2_lpdf_vjp(y, loc, cov)
+    rows = h // world
+    for rank, lp, gy, mn in results:
+        np.testing.assert_allclose(lp, lp_ref, rtol=RTOL)
+        np.testing.assert_allclose(gy, gy_ref[rank * rows:(rank + 1) * rows], rtol=RTOL, atol=RTOL * np.abs(gy_ref).max())
+        np.testing.assert_allclose(mn, 0.5 * h * w * cov.min(), rtol=1e-13)
