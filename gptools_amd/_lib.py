@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgptools_hip.so")
+# GPT_LIB: another build of the same library (tuning variants made by scripts/mkvar.sh)
+LIB_PATH = os.environ.get("GPT_LIB") or os.path.join(_HERE, "libgptools_hip.so")
 
 GPT_OK, GPT_ERR_NOT_PD, GPT_ERR_SHAPE, GPT_ERR_UNSUPPORTED = 0, 1, 2, 3
 GPT_ROW_MAJOR, GPT_COL_MAJOR = 0, 1

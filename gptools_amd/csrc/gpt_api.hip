@@ -149,6 +149,10 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
     // unit after the other on the context's stream. (Overlapping pass B of one lattice with the row passes of
     // its neighbours on a second stream, with and without CU masks, was measured and is slower: pass B has no
     // idle CU resources to share and slows down in proportion to the CUs it gives up -- DESIGN.md section 6.)
+    if (path == 1) {
+        const int R = gpt_pow2_sub_radix(op, a.H, a.W);
+        if (R && (rc = get_twiddles(c, a.H / R, &a.tw_sub)) != GPT_OK) return rc;
+    }
     const size_t per = path == 1 ? gpt_pow2_workspace_bytes(a.H, a.W) : gpt_generic_workspace_bytes(a.H, a.W);
     int64_t chunk = (int64_t)((size_t)(128u << 20) / per);
     if (chunk < 1) chunk = 1;

@@ -73,6 +73,8 @@ struct LatArgs {
     // col0 .. col0 + ncols - 1 of the lattice; the spectrum buffer holds just those, cov / out_cov keep the
     // lattice's own H x Wf layout. ncols == 0: the whole lattice.
     int col0, ncols;
+    // Twiddle table w_{H/4}^m of the sub-line column kernels (gpt_pow2_sub.h); null: whole-column kernels only.
+    const cplx* tw_sub;
 };
 
 // ---------------------------------------------------------------------------------------------------

@@ -12,6 +12,9 @@ hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st);
 #define GPT_WS_PAD 8
 bool gpt_pow2_supported(int H, int W);
 size_t gpt_pow2_workspace_bytes(int H, int W);
+// Sub-line variant of the three passes (gpt_pow2_sub.h): radix R of the step across rows (2 or 4), 0 = the
+// whole-column kernels. Needs LatArgs::tw_sub = twiddles of length H / R.
+int gpt_pow2_sub_radix(int op, int H, int W);
 // Workgroups of the persistent column kernel (= partials per lattice) when it may use `cus` CUs.
 int gpt_pow2_col_blocks(int H, int W, int cus);
 // One pass of the three: 0 = row forward (A), 1 = column (B; plus the second reduction stage when the op has

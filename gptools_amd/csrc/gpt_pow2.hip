@@ -1,5 +1,6 @@
 // Dispatcher of the power-of-two three-pass path (kernels in gpt_pow2_impl.h / gpt_pow2_n.hip).
-#include "gpt_pow2_impl.h"
+#include "gpt_pow2_sub.h"
+#include <cstdlib>
 
 namespace {
 bool is_pow2_in_range(int n) { return n >= 256 && n <= 16384 && (n & (n - 1)) == 0; }
@@ -16,7 +17,49 @@ template <typename F> hipError_t by_size(int n, F f) {
     default: return hipErrorInvalidValue;
     }
 }
+template <typename F> hipError_t sub_by_size(int n, F f) {
+    switch (n) {
+    case 256: return f(pow2::LaunchSub<256>());
+    case 512: return f(pow2::LaunchSub<512>());
+    case 1024: return f(pow2::LaunchSub<1024>());
+    case 2048: return f(pow2::LaunchSub<2048>());
+    case 4096: return f(pow2::LaunchSub<4096>());
+    default: return hipErrorInvalidValue;
+    }
+}
+#ifndef GPT_SUB_DEFAULT
+#define GPT_SUB_DEFAULT 2
+#endif
+// Radix of the step across rows: GPT_SUBLINE=0 keeps the whole-column kernels, 2 / 4 pick a variant (A/B timing).
+int sub_choice() {
+    static const int r = [] {
+        const char* e = getenv("GPT_SUBLINE");
+        if (!e) return GPT_SUB_DEFAULT;
+        return e[0] == '0' ? 0 : (e[0] == '4' ? 4 : 2);
+    }();
+    return r;
+}
 } // namespace
+
+// Sub-line variant (gpt_pow2_sub.h): fused value + gradient ops on whole lattices whose rows fit the
+// two-halves row kernels and whose columns split into four sub-lines of 256..2048 points.
+int gpt_pow2_sub_radix(int op, int H, int W) {
+    const int r = sub_choice();
+    if (r == 0 || !op_is_lpdf_vjp(op) || !gpt_pow2_supported(H, W)) return 0;
+    if (r == 4) {
+        if (!(W == 1024 || W == 2048 || W == 4096)) return 0;
+        return (H >= 1024 && H <= 8192) ? 4 : 0;
+    }
+    return (H >= 512 && H <= 8192) ? 2 : 0; // sub-lines of 256..4096 points, any row length
+}
+static int sub_col_blocks(int R, int H, int W, int cus) {
+    int nb = 1;
+    (void)sub_by_size(H / R, [&](auto l) {
+        nb = decltype(l)::col_blocks(R, W / 2, cus);
+        return hipSuccess;
+    });
+    return nb;
+}
 
 // Rows up to 16384 points (one line per 1024-thread workgroup). Columns up to 8192: the packed column 0 of
 // the column pass needs a whole complex column in LDS (H * 16 bytes).
@@ -29,12 +72,21 @@ size_t gpt_pow2_workspace_bytes(int H, int W) {
     return ws_spec_elems(H, W) * sizeof(cplx) + 4 * (size_t)H * sizeof(double);
 }
 
-int gpt_pow2_col_blocks(int H, int W, int cus) {
+static int whole_col_blocks(int H, int W, int cus) {
     int nb = 1;
     (void)by_size(H, [&](auto l) {
         nb = decltype(l)::col_blocks(W, cus);
         return hipSuccess;
     });
+    return nb;
+}
+// upper bound over the kernels a lattice of this shape may run (sizes the partials buffer)
+int gpt_pow2_col_blocks(int H, int W, int cus) {
+    int nb = whole_col_blocks(H, W, cus);
+    if (const int R = gpt_pow2_sub_radix(OP_LPDF_VJP, H, W)) {
+        const int ns = sub_col_blocks(R, H, W, cus);
+        if (ns > nb) nb = ns;
+    }
     return nb;
 }
 
@@ -43,7 +95,9 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
     if (!gpt_pow2_supported(a.H, a.W)) return hipErrorInvalidValue;
     const int wstride = a.W / 2 + GPT_WS_PAD;
     const double n = (double)a.H * (double)a.W;
-    const int nblk = gpt_pow2_col_blocks(a.H, a.W, col_cus);
+    const int R = (a.ncols == 0 && a.tw_sub) ? gpt_pow2_sub_radix(op, a.H, a.W) : 0;
+    const bool sub = R != 0;
+    const int nblk = sub ? sub_col_blocks(R, a.H, a.W, col_cus) : whole_col_blocks(a.H, a.W, col_cus);
     const bool reduces = (op != OP_RFFT2 && op != OP_INV_RFFT2);
     const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op));
     const double add = -0.5 * n * 1.8378770664093454836;
@@ -51,10 +105,29 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
     // for the fused log-density gradient
     double* edge = reinterpret_cast<double*>(ws + (size_t)a.batch * ws_spec_elems(a.H, a.W));
     const int edge_flags = ((op_has_fwd(op) && a.cov) ? 1 : 0) | ((op == OP_LPDF_VJP && a.out_cov) ? 2 : 0);
+    if (sub) {
+        if (pass == 0) {
+            if (R == 2)
+                return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, 1, ws, wstride, (edge_flags & 1) ? edge : nullptr, true, st); });
+            return sub_by_size(a.W, [&](auto l) { return decltype(l)::row_fwd4(a, 1, ws, wstride, (edge_flags & 1) ? edge : nullptr, st); });
+        }
+        if (pass == 1)
+            return sub_by_size(a.H / R, [&](auto l) {
+                return decltype(l)::colsub(op, a, R, ws, wstride, a.tw_sub, partials, nblk,
+                                           edge_flags ? edge : nullptr, edge_flags, st);
+            });
+        if (pass == 2) {
+            const FinArgs fin = {partials, nblk, add, a.out_lpdf, a.min_eig};
+            if (R == 2)
+                return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, -1.0 / n, 0, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, true, st); });
+            return sub_by_size(a.W, [&](auto l) { return decltype(l)::row_inv4(a, -1.0 / n, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, st); });
+        }
+        return hipErrorInvalidValue;
+    }
     if (pass == 0) {
         if (!op_has_fwd(op)) return hipSuccess;
         const int in_mode = op == OP_RFFT2 ? 0 : (op == OP_INV_VJP ? 2 : 1);
-        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, in_mode, ws, wstride, (edge_flags & 1) ? edge : nullptr, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, in_mode, ws, wstride, (edge_flags & 1) ? edge : nullptr, false, st); });
     }
     if (pass == 1) {
         hipError_t e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, ws, wstride, partials, nblk, edge_flags ? edge : nullptr, edge_flags, st); });
@@ -79,7 +152,7 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
         if (op == OP_INV_RFFT2) alpha = 1.0 / n;
         else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
         else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
-        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, false, st); });
     }
     return hipErrorInvalidValue;
 }
@@ -102,16 +175,16 @@ int gpt_pow2_col_tile(int H) {
 hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, int ld, double alpha, double* partials,
                               int cus, hipStream_t st) {
     if (pass == 0)
-        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, a.loc ? 1 : 0, spec, ld, nullptr, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, a.loc ? 1 : 0, spec, ld, nullptr, false, st); });
     if (pass == 1) {
-        const int nblk = gpt_pow2_col_blocks(a.H, 2 * a.ncols, cus); // tiles = ncols / tile width
+        const int nblk = whole_col_blocks(a.H, 2 * a.ncols, cus); // tiles = ncols / tile width
         hipError_t e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, spec, ld, partials, nblk, nullptr, 0, st); });
         if (e != hipSuccess) return e;
         return gpt_launch_finalize(partials, nblk, 1, 1, 0.0, a.out_lpdf, a.min_eig, st);
     }
     if (pass == 2) {
         const FinArgs fin = {nullptr, 0, 0.0, nullptr, nullptr};
-        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, 0, spec, ld, fin, nullptr, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, 0, spec, ld, fin, nullptr, false, st); });
     }
     return hipErrorInvalidValue;
 }

@@ -189,10 +189,19 @@ template <bool INV> struct Bfly<16, INV> {
 // butterfly u by w^q with w = w_N^{((t + T u) mod NS) * N/(NS R)}: these bases depend on the thread only,
 // so a kernel loads them ONCE (NPRE table look-ups) and no transform issues a global load afterwards --
 // which also keeps the transforms from waiting on outstanding prefetches (vmcnt retires in order).
+// Radix of the stage that starts with NS transformed points: the odd-sized radix (2, 4 or 8, when log2 N is not
+// a multiple of 4) comes FIRST, where NS = 1 means no twiddles at all; every later stage is a radix-16 stage
+// with one twiddle base per register tile.
+constexpr int stage_radix(int n, int ns) {
+    if (ns > 1) return 16;
+    int r = n;
+    while (r > 16) r /= 16;
+    return r;
+}
 template <int N> constexpr int tw_npre() {
     int cnt = 0;
     for (int ns = 1; ns < N;) {
-        const int r = (N / ns) >= 16 ? 16 : (N / ns);
+        const int r = stage_radix(N, ns);
         if (ns > 1) cnt += E / r;
         ns *= r;
     }
@@ -200,8 +209,7 @@ template <int N> constexpr int tw_npre() {
 }
 template <int N, int NS, int IDX>
 __device__ __forceinline__ void tw_load_rec(cplx* w, const cplx* __restrict__ tw, int t) {
-    constexpr int REM = N / NS;
-    constexpr int R = REM >= 16 ? 16 : REM;
+    constexpr int R = stage_radix(N, NS);
     constexpr int T = N / E, U = E / R;
     if constexpr (NS > 1) {
         constexpr int tstep = N / (NS * R);
@@ -256,6 +264,16 @@ __device__ __forceinline__ void stage_bfly(cplx (&v)[E], const cplx* w1) {
     }
 }
 
+// Swizzled LDS position of element t + T*m given rb = phys(t), t < T. Bits 4..7 of t + T*m are (t >> 4) +
+// (T/16) m with no carries between the two terms (T/16 is a power of two above t >> 4), so the XOR mask of
+// position t + T*m is that of t combined with a compile-time constant: 256/T distinct bases per thread and
+// immediate offsets instead of one address register per element.
+template <int T, int SWZ> __device__ __forceinline__ int rd_addr(int rb, int t, int m) {
+    if (SWZ == 0 && T % 16 == 0) return (rb ^ (((T / 16) * m) & 15)) + T * m;
+    if (T % 256 == 0) return rb + T * m;
+    return phys<SWZ>(t + T * m);
+}
+
 // Exchange after a (non-final) stage: scatter the butterfly outputs to their Stockham positions, gather
 // back the elements t + T*m the next stage needs. Real and imaginary parts travel separately, so a line
 // needs N * 8 bytes of LDS (32 KB for N = 4096). A thread carries V register tiles (tile k belongs to
@@ -285,7 +303,7 @@ __device__ __forceinline__ void exchange(cplx (&v)[V][E], const int (&t)[V], dou
     for (int k = 0; k < V; ++k) {
         const int rb = phys<SWZ>(t[k]);
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[k][m].x = lds[(T % 256 == 0) ? rb + T * m : phys<SWZ>(t[k] + T * m)];
+        for (int m = 0; m < E; ++m) v[k][m].x = lds[rd_addr<T, SWZ>(rb, t[k], m)];
     }
     __syncthreads();
 #pragma unroll
@@ -299,15 +317,14 @@ __device__ __forceinline__ void exchange(cplx (&v)[V][E], const int (&t)[V], dou
     for (int k = 0; k < V; ++k) {
         const int rb = phys<SWZ>(t[k]);
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[k][m].y = lds[(T % 256 == 0) ? rb + T * m : phys<SWZ>(t[k] + T * m)];
+        for (int m = 0; m < E; ++m) v[k][m].y = lds[rd_addr<T, SWZ>(rb, t[k], m)];
     }
 }
 
 template <int N, int NS, int IDX, bool INV, int V, int SWZ>
 __device__ __forceinline__ void fft_rec(cplx (&v)[V][E], const int (&t)[V], double* lds,
                                         const cplx (&wpre)[V][tw_npre<N>() > 0 ? tw_npre<N>() : 1]) {
-    constexpr int REM = N / NS;
-    constexpr int R = REM >= 16 ? 16 : REM;
+    constexpr int R = stage_radix(N, NS);
     constexpr int U = E / R;
 #if GPT_TRACE
     constexpr int SIDX = NS == 1 ? 0 : (NS == 16 ? 1 : 2); // stage number (radix-16 plans)
@@ -362,7 +379,10 @@ template <int N> struct Geo {
 
 // pass A --------------------------------------------------------------------------------------------
 // in_mode: 0 = x, 1 = x - loc, 2 = aux
-template <int W>
+// SUB2 (sub-line variant with R = 2, gpt_pow2_sub.h): the workgroup's two rows are r and r + H/2 instead of
+// 2r and 2r + 1, and the first radix-2 step of the column transform is done on them before they are stored:
+// u0 = S[r] + S[r + H/2] -> workspace row r, u1 = (S[r] - S[r + H/2]) w_H^r -> workspace row H/2 + r.
+template <int W, bool SUB2 = false>
 __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a, int in_mode, cplx* __restrict__ ws,
                                                                       int wstride, double* __restrict__ edge) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -376,8 +396,9 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
     const bool active = r < npairs;
     const int rr = active ? r : 0;
     const double* src = in_mode == 2 ? a.aux + b * a.aux_bs : a.x + b * a.x_bs;
-    const double* r0 = src + (int64_t)(2 * rr) * W;
-    const double* r1 = r0 + W;
+    const int ra = SUB2 ? rr : 2 * rr, rb = SUB2 ? rr + H / 2 : 2 * rr + 1; // the two rows of this line
+    const double* r0 = src + (int64_t)ra * W;
+    const double* r1 = src + (int64_t)rb * W;
     cplx wpre[tw_npre<W>()];
     tw_load<W>(wpre, a.pw.tw, t);
     cplx v[E];
@@ -385,8 +406,8 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
     for (int m = 0; m < E; ++m) // read once: non-temporal, the cache space is worth more to the workspace (-20 us)
         v[m] = make_double2(__builtin_nontemporal_load(r0 + t + T * m), __builtin_nontemporal_load(r1 + t + T * m));
     if (in_mode == 1 && a.loc) {
-        const double* l0 = a.loc + b * a.loc_bs + (int64_t)(2 * rr) * W;
-        const double* l1 = l0 + W;
+        const double* l0 = a.loc + b * a.loc_bs + (int64_t)ra * W;
+        const double* l1 = a.loc + b * a.loc_bs + (int64_t)rb * W;
 #pragma unroll
         for (int m = 0; m < E; ++m) {
             v[m].x -= l0[t + T * m]; // loc may be shared by the whole batch: ordinary loads
@@ -418,33 +439,46 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
     if (edge && a.cov && t == 0) {
         // stage the two edge columns of cov contiguously for the column pass (its packed column 0 would
         // otherwise gather them, 64 lines per load instruction, while everybody else streams)
-        const double* cv = a.cov + b * a.cov_bs + (int64_t)(2 * rr) * (W / 2 + 1);
-        double* e = edge + b * 4 * (int64_t)H + 2 * rr;
-        e[0] = cv[0];
-        e[1] = cv[W / 2 + 1];
-        e[H] = cv[W / 2];
-        e[H + 1] = cv[W / 2 + 1 + W / 2];
+        const double* cv = a.cov + b * a.cov_bs;
+        const int wf = W / 2 + 1;
+        double* e = edge + b * 4 * (int64_t)H;
+        e[ra] = cv[(int64_t)ra * wf];
+        e[rb] = cv[(int64_t)rb * wf];
+        e[H + ra] = cv[(int64_t)ra * wf + W / 2];
+        e[H + rb] = cv[(int64_t)rb * wf + W / 2];
     }
-    cplx* s0 = ws + ((int64_t)b * H + 2 * rr) * wstride;
-    cplx* s1 = s0 + wstride;
+    cplx* s0 = ws + ((int64_t)b * H + ra) * wstride;
+    cplx* s1 = ws + ((int64_t)b * H + rb) * wstride;
+    cplx wr = make_double2(1.0, 0.0);
+    if (SUB2) wr = a.ph.tw[rr]; // uniform: w_H^r
 #pragma unroll
     for (int m = 0; m < E / 2; ++m) {
         const int j = t + T * m;
         const cplx z = v[m];
+        cplx za, zb;
         if (j == 0) {
             const cplx zn = v[E / 2]; // Z[W/2] lives in the same thread (t == 0, m == E/2)
-            s0[0] = make_double2(z.x, zn.x);
-            s1[0] = make_double2(z.y, zn.y);
+            za = make_double2(z.x, zn.x);
+            zb = make_double2(z.y, zn.y);
         } else {
-            s0[j] = make_double2(0.5 * (z.x + zc[m].x), 0.5 * (z.y - zc[m].y));
-            s1[j] = make_double2(0.5 * (z.y + zc[m].y), -0.5 * (z.x - zc[m].x));
+            za = make_double2(0.5 * (z.x + zc[m].x), 0.5 * (z.y - zc[m].y));
+            zb = make_double2(0.5 * (z.y + zc[m].y), -0.5 * (z.x - zc[m].x));
+        }
+        if (SUB2) {
+            s0[j] = cadd(za, zb);
+            s1[j] = cmul(csub(za, zb), wr);
+        } else {
+            s0[j] = za;
+            s1[j] = zb;
         }
     }
 }
 
 // pass C --------------------------------------------------------------------------------------------
 // out = alpha * value (+ loc when add_loc)
-template <int W>
+// SUB2: the mirror image of row_fwd_kernel<W, true>: S[r] = v0 + conj(w_H^r) v1, S[r + H/2] = v0 - conj(w_H^r) v1
+// with v0, v1 the workspace rows r and H/2 + r.
+template <int W, bool SUB2 = false>
 __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a, double alpha, int add_loc,
                                                                       const cplx* __restrict__ ws, int wstride,
                                                                       FinArgs fin, const double* __restrict__ edge) {
@@ -457,27 +491,31 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
     const int r = blockIdx.x * LINES + line;
     const bool active = r < H / 2;
     const int rr = active ? r : 0;
-    const cplx* s0 = ws + ((int64_t)b * H + 2 * rr) * wstride;
-    const cplx* s1 = s0 + wstride;
+    const int ra = SUB2 ? rr : 2 * rr, rb = SUB2 ? rr + H / 2 : 2 * rr + 1;
+    const cplx* s0 = ws + ((int64_t)b * H + ra) * wstride;
+    const cplx* s1 = ws + ((int64_t)b * H + rb) * wstride;
+    cplx wr = make_double2(1.0, 0.0);
+    if (SUB2) wr = cconj(a.ph.tw[rr]);
     cplx wpre[tw_npre<W>()];
     tw_load<W>(wpre, a.pw.tw, t);
     cplx v[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) {
         const int j = t + T * m;
+        const int q = W - j; // 1 .. W/2 when m >= E/2
+        const int col = m < E / 2 ? j : (q == W / 2 ? 0 : q);
+        cplx A = s0[col], B = s1[col];
+        if (SUB2) {
+            const cplx u = cmul(B, wr);
+            B = csub(A, u);
+            A = cadd(A, u);
+        }
         if (m < E / 2) {
-            const cplx A = s0[j], B = s1[j];
             if (j == 0) v[m] = make_double2(A.x, B.x); // DC terms are real
             else v[m] = make_double2(A.x - B.y, A.y + B.x);
         } else {
-            const int q = W - j; // 1 .. W/2
-            if (q == W / 2) {
-                const cplx A = s0[0], B = s1[0];
-                v[m] = make_double2(A.y, B.y); // Nyquist terms ride in the imaginary slot of column 0
-            } else {
-                const cplx A = s0[q], B = s1[q];
-                v[m] = make_double2(A.x + B.y, -A.y + B.x); // conj(A) + i conj(B)
-            }
+            if (q == W / 2) v[m] = make_double2(A.y, B.y); // Nyquist terms ride in the imaginary slot of column 0
+            else v[m] = make_double2(A.x + B.y, -A.y + B.x); // conj(A) + i conj(B)
         }
     }
     fft_regs<W, true>(v, t, lds, wpre);
@@ -489,18 +527,19 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
     if (!active) return;
     if (edge && a.out_cov && t == 0) {
         // the column pass left d/dcov of the two edge columns contiguous: put rows 2rr, 2rr+1 in place
-        const double* e = edge + b * 4 * (int64_t)H + 2 * (int64_t)H + 2 * rr;
-        double* oc = a.out_cov + b * (int64_t)H * (W / 2 + 1) + (int64_t)(2 * rr) * (W / 2 + 1);
-        oc[0] = e[0];
-        oc[W / 2 + 1] = e[1];
-        oc[W / 2] = e[H];
-        oc[W / 2 + 1 + W / 2] = e[H + 1];
+        const double* e = edge + b * 4 * (int64_t)H + 2 * (int64_t)H;
+        const int wf = W / 2 + 1;
+        double* oc = a.out_cov + b * (int64_t)H * wf;
+        oc[(int64_t)ra * wf] = e[ra];
+        oc[(int64_t)rb * wf] = e[rb];
+        oc[(int64_t)ra * wf + W / 2] = e[H + ra];
+        oc[(int64_t)rb * wf + W / 2] = e[H + rb];
     }
-    double* o0 = a.out + b * (int64_t)H * W + (int64_t)(2 * rr) * W;
-    double* o1 = o0 + W;
+    double* o0 = a.out + b * (int64_t)H * W + (int64_t)ra * W;
+    double* o1 = a.out + b * (int64_t)H * W + (int64_t)rb * W;
     if (add_loc && a.loc) {
-        const double* l0 = a.loc + b * a.loc_bs + (int64_t)(2 * rr) * W;
-        const double* l1 = l0 + W;
+        const double* l0 = a.loc + b * a.loc_bs + (int64_t)ra * W;
+        const double* l1 = a.loc + b * a.loc_bs + (int64_t)rb * W;
 #pragma unroll
         for (int m = 0; m < E; ++m) {
             o0[t + T * m] = fma(alpha, v[m].x, l0[t + T * m]);
@@ -706,9 +745,11 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
 }
 
 template <int N> struct Launch {
-    static hipError_t row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, hipStream_t st);
+    // sub2: the R = 2 sub-line variant of the row kernels (rows r and r + H/2 per workgroup)
+    static hipError_t row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, bool sub2,
+                              hipStream_t st);
     static hipError_t row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
-                              const FinArgs& fin, const double* edge, hipStream_t st);
+                              const FinArgs& fin, const double* edge, bool sub2, hipStream_t st);
     static hipError_t col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg, double* edge,
                           int edge_flags, hipStream_t st);
     // grid of the persistent column kernel = number of per-lattice partials, one workgroup per CU it may use

@@ -21,29 +21,38 @@ template <typename K> hipError_t raise_lds(K kernel, size_t lds) {
 } // namespace
 
 template <>
-hipError_t Launch<GPT_N>::row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge,
+hipError_t Launch<GPT_N>::row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, bool sub2,
                                   hipStream_t st) {
     constexpr int W = GPT_N;
     const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(double);
-    hipError_t e = raise_lds(row_fwd_kernel<W>, lds);
+    hipError_t e = sub2 ? raise_lds(row_fwd_kernel<W, true>, lds) : raise_lds(row_fwd_kernel<W, false>, lds);
     if (e != hipSuccess) return e;
     const int npairs = a.H / 2;
     dim3 grid((npairs + Geo<W>::ROW_LINES - 1) / Geo<W>::ROW_LINES, (unsigned)a.batch);
-    hipLaunchKernelGGL(row_fwd_kernel<W>, grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, in_mode, ws, wstride, edge);
+    if (sub2)
+        hipLaunchKernelGGL((row_fwd_kernel<W, true>), grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, in_mode, ws, wstride,
+                           edge);
+    else
+        hipLaunchKernelGGL((row_fwd_kernel<W, false>), grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, in_mode, ws, wstride,
+                           edge);
     return hipGetLastError();
 }
 
 template <>
 hipError_t Launch<GPT_N>::row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
-                                  const FinArgs& fin, const double* edge, hipStream_t st) {
+                                  const FinArgs& fin, const double* edge, bool sub2, hipStream_t st) {
     constexpr int W = GPT_N;
     const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(double);
-    hipError_t e = raise_lds(row_inv_kernel<W>, lds);
+    hipError_t e = sub2 ? raise_lds(row_inv_kernel<W, true>, lds) : raise_lds(row_inv_kernel<W, false>, lds);
     if (e != hipSuccess) return e;
     const int npairs = a.H / 2;
     dim3 grid((npairs + Geo<W>::ROW_LINES - 1) / Geo<W>::ROW_LINES, (unsigned)a.batch);
-    hipLaunchKernelGGL(row_inv_kernel<W>, grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, alpha, add_loc, ws, wstride, fin,
-                       edge);
+    if (sub2)
+        hipLaunchKernelGGL((row_inv_kernel<W, true>), grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, alpha, add_loc, ws,
+                           wstride, fin, edge);
+    else
+        hipLaunchKernelGGL((row_inv_kernel<W, false>), grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, alpha, add_loc, ws,
+                           wstride, fin, edge);
     return hipGetLastError();
 }
 

@@ -1,0 +1,470 @@
+// Sub-line variant of the power-of-two three-pass path: the column transform of length H = R * HS is split
+// into one radix-R step ACROSS rows, done where the rows already sit in registers (epilogue of pass A,
+// prologue of pass C), and R independent sub-line transforms of length HS in pass B.
+//
+//   forward (decimation in frequency), column x[i], i = r + HS p:
+//       u_q[r]    = w_H^{r q} * sum_p x[r + HS p] w_R^{p q}            (pass A', stored at workspace row q HS + r)
+//       X[R k + q] = FFT_HS(u_q)[k]                                    (pass B', sub-line q; logical row R k + q)
+//   inverse (decimation in time), unnormalised:
+//       v_q       = IFFT_HS(Y[R . + q])                                (pass B', in place)
+//       y[r + HS p] = sum_q w_R^{-p q} w_H^{-r q} v_q[r]               (pass C')
+//
+// Why: a pass-B tile of TC columns x HS rows has to fit the register file, so a 4x shorter line makes the tile
+// 2x wider (8 columns = one full 128-byte line of the spectrum per row instead of 64-byte pieces; the pass is
+// bound by line requests, gpt_pow2_impl.h) AND 2x smaller (128 KB), so that two workgroups share a CU and one
+// computes while the other waits for memory. The row kernels pay for it with one LDS hop of half their data.
+//
+// Hermitian pairing on the packed column 0 (rows i and H - i meet in the elementwise stage): i = R k + q pairs
+// with R (HS - k) for q = 0 and with R (HS - 1 - k) + (R - q) otherwise, i.e. sub-line q pairs with sub-line
+// R - q. The first R/2 + 1 workgroups of pass B' take that one column (col0_role), all tiles skip it.
+#pragma once
+#include "gpt_pow2_impl.h"
+
+namespace pow2 {
+
+#ifndef GPT_SUB_NOROLE
+#define GPT_SUB_NOROLE 0
+#endif
+constexpr int SUB_R = 4; // rows a pass-A'/C' workgroup combines (radix of the step across rows)
+
+template <int HS, int V_, int THREADS_> struct GeoS {
+    static constexpr int T = HS / E;
+    static constexpr int V = V_;
+    static constexpr int TP = T / V;
+    static constexpr int THREADS = THREADS_;
+    static constexpr int TC = THREADS / TP; // adjacent packed columns per tile
+    static constexpr int SKEW = 4;
+    static constexpr int LINES = THREADS / T; // single-tile lines the workgroup can hold (col0_role)
+    static_assert(THREADS % TP == 0 && TC >= 1, "tile geometry");
+    static_assert(LINES >= 2, "col0_role needs two lines");
+    static constexpr size_t lds_bytes() {
+        const size_t a = (size_t)TC * (HS + SKEW) * sizeof(double), b = 2 * (size_t)HS * sizeof(cplx),
+                     c = (size_t)LINES * HS * sizeof(double);
+        return a > b ? (a > c ? a : c) : (b > c ? b : c);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Packed column 0 of sub-lines q and R - q (q = blockIdx-supplied, 0 <= q <= R/2). Every thread of the
+// workgroup walks through the same barriers; threads beyond the two live lines transform zeros in LDS
+// regions of their own.
+template <int HS, int THREADS, int OP>
+__device__ __forceinline__ void col0_role(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int R, int q,
+                                          cplx* __restrict__ wsb, int wstride, const cplx* __restrict__ tws,
+                                          unsigned char* smem, EwAcc& acc) {
+    constexpr int T = HS / E;
+    const int H = a.H;
+    const int line = threadIdx.x / T, t = threadIdx.x - line * T;
+    const bool paired = (q != 0) && (2 * q != R);
+    const bool live = line == 0 || (line == 1 && paired);
+    const int qrow = line == 0 ? q : R - q;
+    double* lds = reinterpret_cast<double*>(smem) + (size_t)line * HS;
+    cplx* lds0 = reinterpret_cast<cplx*>(smem); // [2][HS] complex, once the transforms are done with LDS
+    cplx wpre[tw_npre<HS>() > 0 ? tw_npre<HS>() : 1];
+    tw_load<HS>(wpre, tws, t);
+    cplx v[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m)
+        v[m] = (live && op_has_fwd(OP)) ? wsb[(unsigned)(qrow * HS + t + T * m) * (unsigned)wstride]
+                                        : make_double2(0.0, 0.0);
+    if (op_has_fwd(OP)) fft_regs<HS, false>(v, t, lds, wpre);
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) lds0[line * HS + t + T * m] = v[m];
+    }
+    __syncthreads();
+    {
+        // pairs: q == 0: (k, HS - k), k = 0..HS/2 (two self pairs); q == R/2: (k, HS - 1 - k), k < HS/2;
+        // otherwise (line 0 [k], line 1 [HS - 1 - k]) for every k
+        const int npairs = q == 0 ? HS / 2 + 1 : (paired ? HS : HS / 2);
+#pragma unroll 1
+        for (int kk = threadIdx.x; kk < npairs; kk += THREADS) {
+            int ia, ib; // LDS slots of the pair; row = logical row (<= H/2) of slot ia... or of slot ib
+            bool self = false, swap = false;
+            int row;
+            if (q == 0) {
+                ia = kk;
+                ib = (HS - kk) & (HS - 1);
+                self = (ia == ib);
+                row = R * kk;
+            } else if (!paired) {
+                ia = kk;
+                ib = HS - 1 - kk;
+                row = R * kk + q;
+            } else {
+                ia = kk;
+                ib = HS + (HS - 1 - kk);
+                row = R * kk + q;
+                if (2 * row > H) { // the mirror row is the one below H/2
+                    row = H - row;
+                    swap = true;
+                }
+            }
+            cplx Zk = lds0[swap ? ib : ia];
+            cplx Zm = self ? Zk : lds0[swap ? ia : ib];
+            ew_packed0_c<OP>(a, L, P, row, Zk, Zm, load_edge_cov<OP>(a, L, P, row), acc);
+            if (op_has_inv(OP)) {
+                lds0[swap ? ib : ia] = Zk;
+                if (!self) lds0[swap ? ia : ib] = Zm;
+            }
+        }
+    }
+    __syncthreads();
+    if (op_has_inv(OP)) {
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) v[m] = lds0[line * HS + t + T * m];
+        }
+        // (the first exchange of the transform starts with a barrier: lds0 is free by then)
+        fft_regs<HS, true>(v, t, lds, wpre);
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) wsb[(unsigned)(qrow * HS + t + T * m) * (unsigned)wstride] = v[m];
+        }
+    }
+    __syncthreads();
+}
+
+// pass B' -------------------------------------------------------------------------------------------
+// Tiles: (sub-line q, TC adjacent packed columns), ntq column tiles per sub-line; tile = q * ntq + ct.
+// Same persistent walk and XCD-aware order as col_kernel.
+template <int HS, int V, int THREADS, int OP>
+__global__ void __launch_bounds__(THREADS, (V == 1 ? 4 : 2))  // waves per SIMD the register budget must allow
+    colsub_kernel(LatArgs a, int R, cplx* __restrict__ ws, int wstride, const cplx* __restrict__ tws,
+                  double* __restrict__ partials, int ntq, double* __restrict__ edge, int edge_flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = GeoS<HS, V, THREADS>;
+    constexpr int T = G::T, TC = G::TC, TP = G::TP;
+    constexpr int NPRE = tw_npre<HS>();
+    constexpr bool NEEDS_COV = (OP != OP_RFFT2 && OP != OP_INV_RFFT2);
+    constexpr int CVN = V == 1 ? 8 : E; // cov values requested together (register budget of the 128-VGPR build)
+    const int c = threadIdx.x % TC, tp = threadIdx.x / TC;
+    double* lds = reinterpret_cast<double*>(smem) + (size_t)c * (HS + G::SKEW);
+    double* red = reinterpret_cast<double*>(smem);
+    const int64_t b = blockIdx.y;
+    const int H = a.H;
+    const ZLayout L = make_layout(a);
+    EwPtrs P = make_ptrs(a, b);
+    if (edge) {
+        if (edge_flags & 1) P.edge_cov = edge + b * 4 * (int64_t)H;
+        if (edge_flags & 2) P.edge_dcov = edge + b * 4 * (int64_t)H + 2 * (int64_t)H;
+    }
+    cplx* wsb = ws + (int64_t)b * H * wstride;
+    EwAcc acc;
+    acc_init(acc);
+    if (!GPT_SUB_NOROLE && a.col0 == 0 && (int)blockIdx.x <= R / 2) {
+        col0_role<HS, THREADS, OP>(a, L, P, R, (int)blockIdx.x, wsb, wstride, tws, smem, acc);
+        acc_fold(acc);
+    }
+    const int ntiles = R * ntq;
+    int first, step, count;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        if ((nwg & 7) == 0 && (ntiles & 7) == 0) {
+            const int per = ntiles >> 3, i = bid >> 3;
+            step = nwg >> 3;
+            first = (bid & 7) * per + i;
+            count = i < per ? (per - i + step - 1) / step : 0;
+        } else {
+            step = nwg;
+            first = bid;
+            count = bid < ntiles ? (ntiles - bid + step - 1) / step : 0;
+        }
+    }
+#pragma unroll 1
+    for (int r = 0; r < count; ++r) {
+        const int tile = first + r * step;
+        const int q = tile / ntq, ct = tile - q * ntq;
+        const int j0 = ct * TC;
+        const int jl = j0 + c;      // packed column inside the spectrum buffer
+        const int jp = a.col0 + jl; // ... and inside the lattice
+        const bool skip = (jp == 0); // the packed column 0 belongs to col0_role
+        const int rowq = q * HS;
+        int tl[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            tl[k] = tp + k * TP;
+            asm volatile("" : "+v"(tl[k]));
+        }
+        // twiddle bases: (re)loaded per tile from the cached table rather than kept across the loop
+        cplx wl[V][NPRE > 0 ? NPRE : 1];
+#pragma unroll
+        for (int k = 0; k < V; ++k) tw_load<HS>(wl[k], tws, tl[k]);
+        cplx v[V][E];
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+#pragma unroll
+            for (int m = 0; m < E; ++m)
+                v[k][m] = (op_has_fwd(OP) && !skip)
+                              ? wsb[(unsigned)(rowq + tl[k] + T * m) * (unsigned)wstride + (unsigned)jl]
+                              : make_double2(0.0, 0.0);
+        if (op_has_fwd(OP)) fft_regs<HS, false, V, 0>(v, tl, lds, wl);
+        if (!skip && !(GPT_ABLATE & 4)) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+#pragma unroll
+                for (int m0 = 0; m0 < E; m0 += CVN) {
+                    double cv[CVN];
+#pragma unroll
+                    for (int m = 0; m < CVN; ++m)
+                        cv[m] = NEEDS_COV ? P.cov[(unsigned)(R * (tl[k] + T * (m0 + m)) + q) * (unsigned)L.Wf + (unsigned)jp]
+                                          : 1.0;
+#pragma unroll
+                    for (int m = 0; m < CVN; ++m) {
+                        v[k][m0 + m] =
+                            ew_interior_c<OP>(a, L, P, R * (tl[k] + T * (m0 + m)) + q, jp, v[k][m0 + m], cv[m], acc);
+                        if ((m & 3) == 3) SCHED_FENCE();
+                    }
+                    SCHED_FENCE();
+                }
+            }
+        }
+        acc_fold(acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (op_has_inv(OP) && !(GPT_ABLATE & 8)) {
+            int t_inv[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                t_inv[k] = tl[k];
+                asm volatile("" : "+v"(t_inv[k]), "+v"(v[0][0].x));
+#pragma unroll
+                for (int i = 0; i < NPRE; ++i) asm volatile("" : "+v"(wl[k][i].x), "+v"(wl[k][i].y), "+v"(v[0][0].x));
+            }
+            fft_regs<HS, true, V, 0>(v, t_inv, lds, wl);
+            if (!skip) {
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+#pragma unroll
+                    for (int m = 0; m < E; ++m)
+                        wsb[(unsigned)(rowq + t_inv[k] + T * m) * (unsigned)wstride + (unsigned)jl] = v[k][m];
+            }
+        }
+    }
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
+        double s = acc.sum, mn = acc.mn;
+        block_sum_min(s, mn, red);
+        if (threadIdx.x == 0) {
+            double* p = partials + ((int64_t)b * gridDim.x + blockIdx.x) * GPT_PART;
+            p[0] = s;
+            p[1] = p[2] = p[3] = p[4] = 0.0;
+            p[5] = mn;
+        }
+    }
+}
+
+// pass A' -------------------------------------------------------------------------------------------
+// One workgroup = base row r: two halves of T = W/16 threads, half h transforms the real rows r + h HS and
+// r + (h + 2) HS as one complex line, splits them into the half spectra S_h and S_{h+2}; then the radix-4
+// step over p: a = S0 + S2, b = S0 - S2 (half 0), c = S1 + S3, d = -i (S1 - S3) (half 1); half 0 needs c,
+// half 1 needs b (one LDS hop); u0 = a + c, u2 = (a - c) w^{2r} (half 0), u1 = (b + d) w^r,
+// u3 = (b - d) w^{3r} (half 1); u_q goes to workspace row q HS + r.
+template <int W>
+__global__ void __launch_bounds__(2 * (W / E), 4)
+    row_fwd4_kernel(LatArgs a, int in_mode, cplx* __restrict__ ws, int wstride, double* __restrict__ edge) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = W / E;
+    const int half = threadIdx.x / T, t = threadIdx.x - half * T;
+    double* lds = reinterpret_cast<double*>(smem) + (size_t)half * W;
+    cplx* ldx = reinterpret_cast<cplx*>(smem); // [2][W/2] complex: the radix-4 hop reuses the exchange regions
+    const int64_t b = blockIdx.y;
+    const int H = a.H, HS = H / SUB_R;
+    const int r = blockIdx.x;
+    const int ra = r + half * HS, rb = ra + 2 * HS;
+    const double* src = in_mode == 2 ? a.aux + b * a.aux_bs : a.x + b * a.x_bs;
+    const double* r0 = src + (int64_t)ra * W;
+    const double* r1 = src + (int64_t)rb * W;
+    cplx wpre[tw_npre<W>()];
+    tw_load<W>(wpre, a.pw.tw, t);
+    cplx v[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m)
+        v[m] = make_double2(__builtin_nontemporal_load(r0 + t + T * m), __builtin_nontemporal_load(r1 + t + T * m));
+    if (in_mode == 1 && a.loc) {
+        const double* l0 = a.loc + b * a.loc_bs + (int64_t)ra * W;
+        const double* l1 = a.loc + b * a.loc_bs + (int64_t)rb * W;
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            v[m].x -= l0[t + T * m];
+            v[m].y -= l1[t + T * m];
+        }
+    }
+    fft_regs<W, false>(v, t, lds, wpre);
+    cplx zc[E / 2];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m].x;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E / 2; ++m) {
+        const int j = t + T * m;
+        zc[m].x = lds[phys(j == 0 ? 0 : W - j)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m].y;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E / 2; ++m) {
+        const int j = t + T * m;
+        zc[m].y = lds[phys(j == 0 ? 0 : W - j)];
+    }
+    if (edge && a.cov && t == 0) {
+        const double* cv = a.cov + b * a.cov_bs;
+        double* e = edge + b * 4 * (int64_t)H;
+        const int wf = W / 2 + 1;
+        e[ra] = cv[(int64_t)ra * wf];
+        e[rb] = cv[(int64_t)rb * wf];
+        e[H + ra] = cv[(int64_t)ra * wf + W / 2];
+        e[H + rb] = cv[(int64_t)rb * wf + W / 2];
+    }
+    // first radix-4 layer on the thread's own two rows
+    cplx s[E / 2], d[E / 2];
+#pragma unroll
+    for (int m = 0; m < E / 2; ++m) {
+        const int j = t + T * m;
+        const cplx z = v[m];
+        cplx za, zb;
+        if (j == 0) {
+            const cplx zn = v[E / 2];
+            za = make_double2(z.x, zn.x);
+            zb = make_double2(z.y, zn.y);
+        } else {
+            za = make_double2(0.5 * (z.x + zc[m].x), 0.5 * (z.y - zc[m].y));
+            zb = make_double2(0.5 * (z.y + zc[m].y), -0.5 * (z.x - zc[m].x));
+        }
+        s[m] = cadd(za, zb);
+        d[m] = csub(za, zb);
+        if (half) d[m] = mul_mi<false>(d[m]);
+    }
+    __syncthreads(); // the split is done reading LDS
+#pragma unroll
+    for (int m = 0; m < E / 2; ++m)
+        ldx[half * (W / 2) + m * T + t] = make_double2(half ? s[m].x : d[m].x, half ? s[m].y : d[m].y);
+    __syncthreads();
+    const int qlo = half, qhi = half + 2;
+    const cplx wlo = a.ph.tw[qlo * r], whi = a.ph.tw[qhi * r]; // uniform: w_H^{q r}, q r < H
+    cplx* slo = ws + ((int64_t)b * H + qlo * HS + r) * wstride;
+    cplx* shi = ws + ((int64_t)b * H + qhi * HS + r) * wstride;
+#pragma unroll
+    for (int m = 0; m < E / 2; ++m) {
+        const int j = t + T * m;
+        const cplx o = ldx[(1 - half) * (W / 2) + m * T + t];
+        cplx ulo, uhi;
+        if (half == 0) {
+            ulo = cadd(s[m], o);
+            uhi = csub(s[m], o);
+        } else {
+            ulo = cadd(o, d[m]);
+            uhi = csub(o, d[m]);
+        }
+        slo[j] = half ? cmul(ulo, wlo) : ulo;
+        shi[j] = cmul(uhi, whi);
+    }
+}
+
+// pass C' -------------------------------------------------------------------------------------------
+// Half 0 loads the four sub-line values at the positions j = t + T m (m < 8), half 1 at the mirror positions
+// W - j of m >= 8; each undoes the radix-4 step (y_p = sum_q i^{p q} conj(w^{q r}) v_q) and merges (y0, y2)
+// and (y1, y3) into the complex lines of the row pairs (r, r + 2 HS) and (r + HS, r + 3 HS); the halves swap
+// the eight values the other one transforms (one LDS hop), then half h runs the inverse line transform of
+// pair h and writes its two real rows.
+template <int W>
+__global__ void __launch_bounds__(2 * (W / E), 4)
+    row_inv4_kernel(LatArgs a, double alpha, const cplx* __restrict__ ws, int wstride, FinArgs fin,
+                    const double* __restrict__ edge) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = W / E;
+    const int half = threadIdx.x / T, t = threadIdx.x - half * T;
+    double* lds = reinterpret_cast<double*>(smem) + (size_t)half * W;
+    cplx* ldx = reinterpret_cast<cplx*>(smem);
+    const int64_t b = blockIdx.y;
+    const int H = a.H, HS = H / SUB_R;
+    const int r = blockIdx.x;
+    const cplx* s0 = ws + ((int64_t)b * H + r) * wstride;
+    const cplx w1 = cconj(a.ph.tw[r]), w2 = cconj(a.ph.tw[2 * r]), w3 = cconj(a.ph.tw[3 * r]);
+    cplx wpre[tw_npre<W>()];
+    tw_load<W>(wpre, a.pw.tw, t);
+    cplx v[E];
+    cplx snd[E / 2];
+    const unsigned qs = (unsigned)HS * (unsigned)wstride;
+#pragma unroll
+    for (int mm = 0; mm < E / 2; ++mm) {
+        // position (column of the packed spectrum) this thread combines
+        const int j = t + T * (mm + (half ? E / 2 : 0));
+        const int pos = half ? W - j : j;           // half 1: 1 .. W/2
+        const bool edgepos = half ? (pos == W / 2) : (j == 0);
+        const unsigned col = edgepos ? 0u : (unsigned)pos;
+        const cplx v0 = s0[col], v1 = cmul(s0[qs + col], w1), v2 = cmul(s0[2 * qs + col], w2),
+                   v3 = cmul(s0[3 * qs + col], w3);
+        const cplx e = cadd(v0, v2), f = csub(v0, v2), g = cadd(v1, v3), h = mul_mi<true>(csub(v1, v3));
+        const cplx y0 = cadd(e, g), y1 = cadd(f, h), y2 = csub(e, g), y3 = csub(f, h);
+        cplx mA, mB;
+        if (half == 0) {
+            if (edgepos) {
+                mA = make_double2(y0.x, y2.x);
+                mB = make_double2(y1.x, y3.x);
+            } else {
+                mA = make_double2(y0.x - y2.y, y0.y + y2.x);
+                mB = make_double2(y1.x - y3.y, y1.y + y3.x);
+            }
+            v[mm] = mA;
+            snd[mm] = mB;
+        } else {
+            if (edgepos) {
+                mA = make_double2(y0.y, y2.y);
+                mB = make_double2(y1.y, y3.y);
+            } else {
+                mA = make_double2(y0.x + y2.y, -y0.y + y2.x);
+                mB = make_double2(y1.x + y3.y, -y1.y + y3.x);
+            }
+            v[E / 2 + mm] = mB;
+            snd[mm] = mA;
+        }
+    }
+#pragma unroll
+    for (int mm = 0; mm < E / 2; ++mm) ldx[half * (W / 2) + mm * T + t] = snd[mm];
+    __syncthreads();
+#pragma unroll
+    for (int mm = 0; mm < E / 2; ++mm) {
+        const cplx o = ldx[(1 - half) * (W / 2) + mm * T + t];
+        if (half == 0) v[E / 2 + mm] = o;
+        else v[mm] = o;
+    }
+    fft_regs<W, true>(v, t, lds, wpre);
+    if (fin.partials && blockIdx.x == 0) {
+        __syncthreads();
+        finalize_block(fin, b, reinterpret_cast<double*>(smem));
+    }
+    const int ra = r + half * HS, rb = ra + 2 * HS;
+    if (edge && a.out_cov && t == 0) {
+        const double* e = edge + b * 4 * (int64_t)H + 2 * (int64_t)H;
+        const int wf = W / 2 + 1;
+        double* oc = a.out_cov + b * (int64_t)H * wf;
+        oc[(int64_t)ra * wf] = e[ra];
+        oc[(int64_t)rb * wf] = e[rb];
+        oc[(int64_t)ra * wf + W / 2] = e[H + ra];
+        oc[(int64_t)rb * wf + W / 2] = e[H + rb];
+    }
+    double* o0 = a.out + b * (int64_t)H * W + (int64_t)ra * W;
+    double* o1 = a.out + b * (int64_t)H * W + (int64_t)rb * W;
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        __builtin_nontemporal_store(alpha * v[m].x, o0 + t + T * m);
+        __builtin_nontemporal_store(alpha * v[m].y, o1 + t + T * m);
+    }
+}
+
+// Host-side launchers, one specialisation per line length (gpt_sub_n.hip).
+template <int N> struct LaunchSub {
+    static hipError_t row_fwd4(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, hipStream_t st);
+    static hipError_t row_inv4(const LatArgs& a, double alpha, const cplx* ws, int wstride, const FinArgs& fin,
+                               const double* edge, hipStream_t st);
+    // N = HS, the sub-line length
+    static hipError_t colsub(int op, const LatArgs& a, int R, cplx* ws, int wstride, const cplx* tws, double* partials,
+                             int nwg, double* edge, int edge_flags, hipStream_t st);
+    static int col_tile();
+    static int col_blocks(int R, int ncols, int cus);
+};
+
+} // namespace pow2

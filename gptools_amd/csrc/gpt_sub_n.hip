@@ -1,0 +1,105 @@
+// Sub-line kernels (gpt_pow2_sub.h), one translation unit per line length: compiled with -DGPT_N=<power of two>.
+// GPT_N is the ROW length of row_fwd4 / row_inv4 and the SUB-LINE length of colsub.
+#include "gpt_pow2_sub.h"
+
+#ifndef GPT_N
+#error "compile with -DGPT_N=<power of two>"
+#endif
+
+namespace pow2 {
+
+namespace {
+template <typename K> hipError_t raise_lds_sub(K kernel, size_t lds) {
+    if (lds <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds);
+}
+// two register tiles per thread at 256 VGPRs; 256-thread workgroups (two share a CU) while a sub-line fits them
+constexpr int SUB_V = 2;
+#ifndef GPT_SUB_T2048
+#define GPT_SUB_T2048 256
+#endif
+constexpr int SUB_THREADS = GPT_N >= 4096 ? 512 : (GPT_N == 2048 ? GPT_SUB_T2048 : 256);
+using GS = GeoS<GPT_N, SUB_V, SUB_THREADS>;
+} // namespace
+
+#if GPT_N >= 1024 && GPT_N <= 4096
+template <>
+hipError_t LaunchSub<GPT_N>::row_fwd4(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge,
+                                      hipStream_t st) {
+    constexpr int W = GPT_N;
+    const size_t lds = 2 * (size_t)W * sizeof(double);
+    hipError_t e = raise_lds_sub(row_fwd4_kernel<W>, lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)(a.H / SUB_R), (unsigned)a.batch);
+    hipLaunchKernelGGL(row_fwd4_kernel<W>, grid, dim3(2 * (W / E)), lds, st, a, in_mode, ws, wstride, edge);
+    return hipGetLastError();
+}
+
+template <>
+hipError_t LaunchSub<GPT_N>::row_inv4(const LatArgs& a, double alpha, const cplx* ws, int wstride, const FinArgs& fin,
+                                      const double* edge, hipStream_t st) {
+    constexpr int W = GPT_N;
+    const size_t lds = 2 * (size_t)W * sizeof(double);
+    hipError_t e = raise_lds_sub(row_inv4_kernel<W>, lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)(a.H / SUB_R), (unsigned)a.batch);
+    hipLaunchKernelGGL(row_inv4_kernel<W>, grid, dim3(2 * (W / E)), lds, st, a, alpha, ws, wstride, fin, edge);
+    return hipGetLastError();
+}
+#else
+template <>
+hipError_t LaunchSub<GPT_N>::row_fwd4(const LatArgs&, int, cplx*, int, double*, hipStream_t) {
+    return hipErrorInvalidValue;
+}
+template <>
+hipError_t LaunchSub<GPT_N>::row_inv4(const LatArgs&, double, const cplx*, int, const FinArgs&, const double*,
+                                      hipStream_t) {
+    return hipErrorInvalidValue;
+}
+#endif
+
+#if GPT_N <= 4096
+template <int OP>
+static hipError_t colsub_t(const LatArgs& a, int R, cplx* ws, int wstride, const cplx* tws, double* partials, int nwg,
+                           double* edge, int edge_flags, hipStream_t st) {
+    constexpr int HS = GPT_N;
+    const size_t lds = GS::lds_bytes();
+    hipError_t e = raise_lds_sub(colsub_kernel<HS, SUB_V, SUB_THREADS, OP>, lds);
+    if (e != hipSuccess) return e;
+    const int ntq = (a.ncols > 0 ? a.ncols : a.W / 2) / GS::TC;
+    dim3 grid((unsigned)nwg, (unsigned)a.batch);
+    hipLaunchKernelGGL((colsub_kernel<HS, SUB_V, SUB_THREADS, OP>), grid, dim3(SUB_THREADS), lds, st, a, R, ws, wstride,
+                       tws, partials, ntq, edge, edge_flags);
+    return hipGetLastError();
+}
+
+template <>
+hipError_t LaunchSub<GPT_N>::colsub(int op, const LatArgs& a, int R, cplx* ws, int wstride, const cplx* tws,
+                                    double* partials, int nwg, double* edge, int edge_flags, hipStream_t st) {
+    switch (op) {
+    case OP_LPDF_VJP: return colsub_t<OP_LPDF_VJP>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    case OP_LPDF_VJP_NOCOV:
+        return colsub_t<OP_LPDF_VJP_NOCOV>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+template <> int LaunchSub<GPT_N>::col_tile() { return GS::TC; }
+template <> int LaunchSub<GPT_N>::col_blocks(int R, int ncols, int cus) {
+    const int ntiles = R * (ncols / GS::TC);
+    int cap = cus * (SUB_THREADS == 256 ? 2 : 1);
+    if (cap >= 8) cap &= ~7;
+    if (cap < R / 2 + 1) cap = R / 2 + 1; // the packed column 0 needs its R/2 + 1 workgroups
+    return ntiles < cap ? (ntiles > R / 2 + 1 ? ntiles : R / 2 + 1) : cap;
+}
+#else
+template <>
+hipError_t LaunchSub<GPT_N>::colsub(int, const LatArgs&, int, cplx*, int, const cplx*, double*, int, double*, int,
+                                    hipStream_t) {
+    return hipErrorInvalidValue;
+}
+template <> int LaunchSub<GPT_N>::col_tile() { return 0; }
+template <> int LaunchSub<GPT_N>::col_blocks(int, int, int) { return 0; }
+#endif
+
+} // namespace pow2

@@ -276,6 +276,7 @@ def test_host_entry_points_col_major(fft):
 # ---- three-pass paths (lattices too large for one workgroup's LDS) ----------------------------------
 BIG_SHAPES = [(256, 256), (256, 512), (512, 256), (1024, 256), (2048, 512), (512, 2048), (8192, 256), (256, 8192),
               (256, 16384),  # every line length of the power-of-two kernels
+              (1024, 1024), (2048, 1024), (1024, 2048), (8192, 1024), (1024, 4096), (4096, 2048),  # sub-line kernels
               (110, 110), (90, 125), (128, 128), (301, 200), (5, 3000), (2500, 6)]  # generic three-pass path
 
 
