@@ -29,6 +29,9 @@
 #ifndef GPT_TRACE
 #define GPT_TRACE 0
 #endif
+#ifndef GPT_PF_COV
+#define GPT_PF_COV 0
+#endif
 #if GPT_TRACE
 // debug builds only (scripts/trace_col.py): phase timestamps (100 MHz clock) of wave 0 of every column workgroup
 __device__ unsigned long long g_col_trace[1024 * 8 * 8];
@@ -414,6 +417,20 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
             v[m].y -= l1[t + T * m];
         }
     }
+    // Touch the cov rows of this line (one dword per 128-byte line): the column pass reads cov in narrow column
+    // tiles right when it needs the values, cold from HBM that is 30 us on its critical path; touched here, in a
+    // streaming kernel, the lines wait for it in the Infinity Cache.
+    int pf0 = 0, pf1 = 0;
+    const bool pf = GPT_PF_COV && SUB2 && edge && a.cov;
+    if (pf) {
+        const int wfb = (W / 2 + 1) * 8;
+        const char* cp = reinterpret_cast<const char*>(a.cov + b * a.cov_bs);
+        const int off = (int)threadIdx.x % T * 128;
+        if (off < wfb) {
+            pf0 = *reinterpret_cast<const int*>(cp + (int64_t)ra * wfb + off);
+            pf1 = *reinterpret_cast<const int*>(cp + (int64_t)rb * wfb + off);
+        }
+    }
     fft_regs<W, false>(v, t, lds, wpre);
     // split the two rows: need Z[j] (own registers) and Z[W - j] (through LDS, re then im)
     cplx zc[E / 2];
@@ -472,6 +489,7 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
             s1[j] = zb;
         }
     }
+    if (pf) asm volatile("" ::"v"(pf0), "v"(pf1)); // keeps the touches; they have long arrived
 }
 
 // pass C --------------------------------------------------------------------------------------------

@@ -22,6 +22,18 @@
 
 namespace pow2 {
 
+#ifndef GPT_SUB_WPS1
+#define GPT_SUB_WPS1 4
+#endif
+#ifndef GPT_STAGGER
+#define GPT_STAGGER 0
+#endif
+#ifndef GPT_COV_ALL
+#define GPT_COV_ALL 0
+#endif
+#ifndef GPT_EXP
+#define GPT_EXP 0
+#endif
 #ifndef GPT_SUB_NOROLE
 #define GPT_SUB_NOROLE 0
 #endif
@@ -130,7 +142,7 @@ __device__ __forceinline__ void col0_role(const LatArgs& a, const ZLayout& L, co
 // Tiles: (sub-line q, TC adjacent packed columns), ntq column tiles per sub-line; tile = q * ntq + ct.
 // Same persistent walk and XCD-aware order as col_kernel.
 template <int HS, int V, int THREADS, int OP>
-__global__ void __launch_bounds__(THREADS, (V == 1 ? 4 : 2))  // waves per SIMD the register budget must allow
+__global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : 2))  // waves per SIMD the register budget must allow
     colsub_kernel(LatArgs a, int R, cplx* __restrict__ ws, int wstride, const cplx* __restrict__ tws,
                   double* __restrict__ partials, int ntq, double* __restrict__ edge, int edge_flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -138,6 +150,9 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? 4 : 2))  // waves per SIMD 
     constexpr int T = G::T, TC = G::TC, TP = G::TP;
     constexpr int NPRE = tw_npre<HS>();
     constexpr bool NEEDS_COV = (OP != OP_RFFT2 && OP != OP_INV_RFFT2);
+    // timing-only experiments (GPT_EXP bits; results wrong): 1 = no d/dcov stores, 2 = no cov loads, 4 = cov and
+    // d/dcov rows addressed with an aligned stride (Wf - 1), 8 = cov read from 64 rows only (cache hits)
+    constexpr int EWOP = (GPT_EXP & 1) && OP == OP_LPDF_VJP ? (int)OP_LPDF_VJP_NOCOV : OP;
     constexpr int CVN = V == 1 ? 8 : E; // cov values requested together (register budget of the 128-VGPR build)
     const int c = threadIdx.x % TC, tp = threadIdx.x / TC;
     double* lds = reinterpret_cast<double*>(smem) + (size_t)c * (HS + G::SKEW);
@@ -145,6 +160,8 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? 4 : 2))  // waves per SIMD 
     const int64_t b = blockIdx.y;
     const int H = a.H;
     const ZLayout L = make_layout(a);
+    ZLayout LE = L;
+    if (GPT_EXP & 4) LE.Wf -= 1;
     EwPtrs P = make_ptrs(a, b);
     if (edge) {
         if (edge_flags & 1) P.edge_cov = edge + b * 4 * (int64_t)H;
@@ -153,6 +170,14 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? 4 : 2))  // waves per SIMD 
     cplx* wsb = ws + (int64_t)b * H * wstride;
     EwAcc acc;
     acc_init(acc);
+#if GPT_STAGGER
+    // Workgroups that share a CU (the second half of the grid lands on the CUs of the first) would otherwise march
+    // in phase: the late starters wait a fraction of a tile time so that one computes while the other loads.
+    if (2 * blockIdx.x >= gridDim.x) {
+#pragma unroll 1
+        for (int i = 0; i < GPT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     if (!GPT_SUB_NOROLE && a.col0 == 0 && (int)blockIdx.x <= R / 2) {
         col0_role<HS, THREADS, OP>(a, L, P, R, (int)blockIdx.x, wsb, wstride, tws, smem, acc);
         acc_fold(acc);
@@ -201,6 +226,24 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? 4 : 2))  // waves per SIMD 
                               : make_double2(0.0, 0.0);
         if (op_has_fwd(OP)) fft_regs<HS, false, V, 0>(v, tl, lds, wl);
         if (!skip && !(GPT_ABLATE & 4)) {
+            if (GPT_COV_ALL) {
+                // every cov value of the tile is requested before the first one is used: the column pass waits
+                // for HBM here (cold reads in narrow pieces), and one long wait is shorter than V
+                double cv[V][E];
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+#pragma unroll
+                    for (int m = 0; m < E; ++m)
+                        cv[k][m] = NEEDS_COV ? P.cov[(unsigned)(R * (tl[k] + T * m) + q) * (unsigned)L.Wf + (unsigned)jp] : 1.0;
+                SCHED_FENCE();
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+#pragma unroll
+                    for (int m = 0; m < E; ++m) {
+                        v[k][m] = ew_interior_c<EWOP>(a, L, P, R * (tl[k] + T * m) + q, jp, v[k][m], cv[k][m], acc);
+                        if ((m & 3) == 3) SCHED_FENCE();
+                    }
+            } else {
 #pragma unroll
             for (int k = 0; k < V; ++k) {
 #pragma unroll
@@ -208,16 +251,18 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? 4 : 2))  // waves per SIMD 
                     double cv[CVN];
 #pragma unroll
                     for (int m = 0; m < CVN; ++m)
-                        cv[m] = NEEDS_COV ? P.cov[(unsigned)(R * (tl[k] + T * (m0 + m)) + q) * (unsigned)L.Wf + (unsigned)jp]
-                                          : 1.0;
+                        cv[m] = (NEEDS_COV && !(GPT_EXP & 2))
+                                    ? P.cov[(unsigned)((R * (tl[k] + T * (m0 + m)) + q) & ((GPT_EXP & 8) ? 63 : 0x7fffffff)) * (unsigned)LE.Wf + (unsigned)jp]
+                                    : 1.0;
 #pragma unroll
                     for (int m = 0; m < CVN; ++m) {
                         v[k][m0 + m] =
-                            ew_interior_c<OP>(a, L, P, R * (tl[k] + T * (m0 + m)) + q, jp, v[k][m0 + m], cv[m], acc);
+                            ew_interior_c<EWOP>(a, LE, P, R * (tl[k] + T * (m0 + m)) + q, jp, v[k][m0 + m], cv[m], acc);
                         if ((m & 3) == 3) SCHED_FENCE();
                     }
                     SCHED_FENCE();
                 }
+            }
             }
         }
         acc_fold(acc);

@@ -15,7 +15,10 @@ template <typename K> hipError_t raise_lds_sub(K kernel, size_t lds) {
                                (int)lds);
 }
 // two register tiles per thread at 256 VGPRs; 256-thread workgroups (two share a CU) while a sub-line fits them
-constexpr int SUB_V = 2;
+#ifndef GPT_SUB_V
+#define GPT_SUB_V 2
+#endif
+constexpr int SUB_V = GPT_SUB_V;
 #ifndef GPT_SUB_T2048
 #define GPT_SUB_T2048 256
 #endif
