@@ -22,6 +22,8 @@ struct gpt_ctx {
     size_t partials_bytes = 0;
     double* sink = nullptr; // write-only dump for gradients the caller did not ask for
     size_t sink_bytes = 0;
+    cplx* ltmp = nullptr; // scratch lines of the long-row passes (gpt_long.hip)
+    size_t ltmp_bytes = 0;
     char* arena = nullptr; // device staging arena of the host-pointer entry points
     size_t arena_bytes = 0;
     double* pinned = nullptr; // small pinned scratch for scalar read-backs
@@ -296,6 +298,7 @@ int gpt_destroy(gpt_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->partials) (void)hipFree(c->partials);
     if (c->arena) (void)hipFree(c->arena);
+    if (c->ltmp) (void)hipFree(c->ltmp);
     if (c->sink) (void)hipFree(c->sink);
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
@@ -362,8 +365,19 @@ int gpt_path_for_shape(int64_t H, int64_t W) { return path_for_shape(H, W); }
 // the two layouts is the caller's (gptools_amd/slab.py: all-to-all over RCCL).
 static int slab_check(gpt_ctx* c, int64_t H, int64_t W) {
     if (!c) return GPT_ERR_SHAPE;
-    if (!gpt_pow2_supported((int)H, (int)W))
-        return fail(c, GPT_ERR_UNSUPPORTED, "slab passes need a power-of-two height in [256, 8192] and width in [256, 16384]");
+    if (H < 1 || W < 1 || H * W > 2147483647LL || !gpt_slab_supported((int)H, (int)W))
+        return fail(c, GPT_ERR_UNSUPPORTED, "slab passes need a power-of-two height and width in [256, 32768]");
+    return GPT_OK;
+}
+// twiddles of the sub-lines and scratch of the long-row passes (no-ops for rows one workgroup holds)
+static int slab_long_rows(gpt_ctx* c, LatArgs& a, int64_t rows, cplx** tmp) {
+    *tmp = nullptr;
+    const int R = gpt_long_row_split_radix(a.W);
+    if (R <= 0) return GPT_OK;
+    int rc = get_twiddles(c, a.W / R, &a.tw_sub);
+    if (rc) return rc;
+    if ((rc = ensure(c, c->ltmp, c->ltmp_bytes, gpt_long_row_tmp_elems(rows, a.W) * sizeof(cplx))) != GPT_OK) return rc;
+    *tmp = c->ltmp;
     return GPT_OK;
 }
 static int slab_cus(gpt_ctx* c) {
@@ -386,8 +400,10 @@ int gpt_slab_rows_fwd(gpt_ctx* c, const double* y, const double* loc, int64_t ro
     if ((rc = make_plan(c, a.W, a.pw)) != GPT_OK) return rc;
     a.x = y;
     a.loc = loc;
+    cplx* tmp = nullptr;
+    if ((rc = slab_long_rows(c, a, rows, &tmp)) != GPT_OK) return rc;
     HIP_TRY(c, gpt_pow2_slab_pass(0, OP_LPDF_VJP, a, reinterpret_cast<cplx*>(spec), (int)ld, 1.0, nullptr,
-                                  slab_cus(c), c->stream));
+                                  slab_cus(c), tmp, c->stream));
     return GPT_OK;
 }
 
@@ -395,7 +411,7 @@ int gpt_slab_cols_lpdf_vjp(gpt_ctx* c, double* spec, int64_t ld, const double* c
                            int64_t W, int64_t col0, int64_t ncols, double* lpdf_partial, double* min_partial) {
     int rc = slab_check(c, H, W);
     if (rc) return rc;
-    const int tile = gpt_pow2_col_tile((int)H);
+    const int tile = gpt_slab_col_tile((int)H);
     if (col0 < 0 || ncols < 1 || col0 + ncols > W / 2 || ncols % tile || col0 % tile || ld < ncols || !spec || !cov ||
         !lpdf_partial) {
         char buf[200];
@@ -413,15 +429,17 @@ int gpt_slab_cols_lpdf_vjp(gpt_ctx* c, double* spec, int64_t ld, const double* c
     a.out_lpdf = lpdf_partial;
     a.min_eig = min_partial;
     const int cus = slab_cus(c);
-    const int nblk = gpt_pow2_col_blocks(a.H, 2 * a.ncols, cus);
+    const int nblk = gpt_slab_col_blocks(a.H, a.ncols, cus);
     if ((rc = ensure(c, c->partials, c->partials_bytes, sizeof(double) * GPT_PART * (size_t)nblk)) != GPT_OK) return rc;
+    if (const int R = gpt_long_col_split_radix(a.H); R > 0)
+        if ((rc = get_twiddles(c, a.H / R, &a.tw_sub)) != GPT_OK) return rc;
     if (!out_cov) {
         const size_t need = sizeof(double) * (size_t)H * (size_t)(W / 2 + 1);
         if ((rc = ensure(c, c->sink, c->sink_bytes, need)) != GPT_OK) return rc;
         a.out_cov = c->sink;
     }
     HIP_TRY(c, gpt_pow2_slab_pass(1, OP_LPDF_VJP, a, reinterpret_cast<cplx*>(spec), (int)ld, 1.0, c->partials, cus,
-                                  c->stream));
+                                  nullptr, c->stream));
     return GPT_OK;
 }
 
@@ -435,8 +453,10 @@ int gpt_slab_rows_inv(gpt_ctx* c, const double* spec, int64_t ld, int64_t rows, 
     LatArgs a = base_args(rows, W, 1, 0);
     if ((rc = make_plan(c, a.W, a.pw)) != GPT_OK) return rc;
     a.out = out;
+    cplx* tmp = nullptr;
+    if ((rc = slab_long_rows(c, a, rows, &tmp)) != GPT_OK) return rc;
     HIP_TRY(c, gpt_pow2_slab_pass(2, OP_LPDF_VJP, a, const_cast<cplx*>(reinterpret_cast<const cplx*>(spec)), (int)ld,
-                                  alpha, nullptr, slab_cus(c), c->stream));
+                                  alpha, nullptr, slab_cus(c), tmp, c->stream));
     return GPT_OK;
 }
 

@@ -25,8 +25,16 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
 // Slab decomposition (gpt_pow2.hip): column-tile width for lines of length H and the three passes on
 // caller-owned spectrum buffers.
 int gpt_pow2_col_tile(int H);
+// Slab passes also take lines of up to 32768 points (four-step route, gpt_long.hip): shapes, radices (0 = the
+// line fits one workgroup, < 0 = unsupported), scratch size of the row passes, column tile / grid of pass 1.
+bool gpt_slab_supported(int H, int W);
+int gpt_long_row_split_radix(int W);
+int gpt_long_col_split_radix(int H);
+size_t gpt_long_row_tmp_elems(int64_t rows, int W);
+int gpt_slab_col_tile(int H);
+int gpt_slab_col_blocks(int H, int ncols, int cus);
 hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, int ld, double alpha, double* partials,
-                              int cus, hipStream_t st);
+                              int cus, cplx* tmp, hipStream_t st);
 
 // --- generic large path (gpt_generic.hip): any H, W whose lines fit LDS
 bool gpt_generic_supported(int H, int W);

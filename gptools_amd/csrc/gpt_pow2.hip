@@ -167,18 +167,112 @@ int gpt_pow2_col_tile(int H) {
     return tc;
 }
 
+// Long lines (gpt_long.hip): rows of more than 16384 points and columns of more than 8192 take the four-step
+// route; GPT_LONG_MIN=<n> sends every line of at least n points (n >= 2048) that way (tests).
+hipError_t gpt_long_rowstep(bool inverse, int R, cplx* spec, int64_t ld, int HS, int ncols, const cplx* twH,
+                            hipStream_t st);
+int gpt_long_row_radix();
+hipError_t gpt_long_row_fwd1(const double* y, const double* loc, int64_t rows, int W, cplx* tmp, const cplx* twW,
+                             hipStream_t st);
+hipError_t gpt_long_row_split(const cplx* tmp, int64_t rows, int W, cplx* spec, int64_t ld, hipStream_t st);
+hipError_t gpt_long_row_merge(const cplx* spec, int64_t ld, int64_t rows, int W, cplx* tmp, hipStream_t st);
+hipError_t gpt_long_row_inv3(const cplx* tmp, int64_t rows, int W, double alpha, double* out, const cplx* twW,
+                             hipStream_t st);
+static int long_min() {
+    static const int v = [] {
+        const char* e = getenv("GPT_LONG_MIN");
+        const int n = e ? atoi(e) : 0;
+        return n >= 2048 ? n : 1 << 30;
+    }();
+    return v;
+}
+static bool pow2_between(int n, int lo, int hi) { return n >= lo && n <= hi && (n & (n - 1)) == 0; }
+// radix of the four-step route for a row of W points (0: one workgroup holds the line)
+int gpt_long_row_split_radix(int W) {
+    if (!pow2_between(W, 256, 32768)) return -1;
+    return (W > 16384 || W >= long_min()) ? gpt_long_row_radix() : 0;
+}
+// ... and for a column of H points: the smallest radix that leaves sub-lines of at most 4096 points
+int gpt_long_col_split_radix(int H) {
+    if (!pow2_between(H, 256, 32768)) return -1;
+    if (H >= long_min()) return 8;
+    if (H <= 8192) return 0;
+    return H / 4096;
+}
+bool gpt_slab_supported(int H, int W) { return gpt_long_row_split_radix(W) >= 0 && gpt_long_col_split_radix(H) >= 0; }
+// complex scratch elements the long-row passes need for `rows` rows of width W (0: none)
+size_t gpt_long_row_tmp_elems(int64_t rows, int W) {
+    return gpt_long_row_split_radix(W) > 0 ? (size_t)(rows / 2) * (size_t)W : 0;
+}
+int gpt_slab_col_tile(int H) {
+    const int R = gpt_long_col_split_radix(H);
+    if (R <= 0) return gpt_pow2_col_tile(H);
+    int tc = 0;
+    (void)sub_by_size(H / R, [&](auto l) {
+        tc = decltype(l)::col_tile();
+        return hipSuccess;
+    });
+    return tc;
+}
+int gpt_slab_col_blocks(int H, int ncols, int cus) {
+    const int R = gpt_long_col_split_radix(H);
+    if (R <= 0) return whole_col_blocks(H, 2 * ncols, cus);
+    int nb = 1;
+    (void)sub_by_size(H / R, [&](auto l) {
+        nb = decltype(l)::col_blocks(R, ncols, cus);
+        return hipSuccess;
+    });
+    return nb;
+}
+
 // The three passes on caller-owned spectrum buffers (slab decomposition of one lattice over several GPUs).
 //   pass 0: rows -> packed half spectrum of `a.H` (= local rows, even) rows of width a.W; spec[rows][ld]
 //   pass 1: column pass of `op` on packed columns a.col0 .. a.col0 + a.ncols - 1, all a.H rows; spec[H][ld];
 //           the per-workgroup partials are summed into a.out_lpdf[0] (no constant added) and a.min_eig[0]
 //   pass 2: spec[rows][ld] -> a.out[rows][W] = alpha * (inverse row transform)
+// Long lines: `tmp` = scratch of gpt_long_row_tmp_elems complex (passes 0, 2), a.tw_sub = twiddles of the
+// sub-line length (W / 8 for the row passes, H / R for the column pass).
 hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, int ld, double alpha, double* partials,
-                              int cus, hipStream_t st) {
+                              int cus, cplx* tmp, hipStream_t st) {
+    if (pass == 0 || pass == 2) {
+        const int RWd = gpt_long_row_split_radix(a.W);
+        if (RWd < 0) return hipErrorInvalidValue;
+        if (RWd > 0) {
+            if (!tmp || !a.tw_sub) return hipErrorInvalidValue;
+            const int64_t rows = a.H, nlines = (rows / 2) * RWd;
+            hipError_t e;
+            if (pass == 0) {
+                e = gpt_long_row_fwd1(a.x, a.loc, rows, a.W, tmp, a.pw.tw, st);
+                if (e != hipSuccess) return e;
+                e = sub_by_size(a.W / RWd, [&](auto l) { return decltype(l)::line_fft(false, tmp, nlines, a.tw_sub, st); });
+                if (e != hipSuccess) return e;
+                return gpt_long_row_split(tmp, rows, a.W, spec, ld, st);
+            }
+            e = gpt_long_row_merge(spec, ld, rows, a.W, tmp, st);
+            if (e != hipSuccess) return e;
+            e = sub_by_size(a.W / RWd, [&](auto l) { return decltype(l)::line_fft(true, tmp, nlines, a.tw_sub, st); });
+            if (e != hipSuccess) return e;
+            return gpt_long_row_inv3(tmp, rows, a.W, alpha, a.out, a.pw.tw, st);
+        }
+    }
     if (pass == 0)
         return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, a.loc ? 1 : 0, spec, ld, nullptr, false, st); });
     if (pass == 1) {
-        const int nblk = whole_col_blocks(a.H, 2 * a.ncols, cus); // tiles = ncols / tile width
-        hipError_t e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, spec, ld, partials, nblk, nullptr, 0, st); });
+        const int R = gpt_long_col_split_radix(a.H);
+        if (R < 0) return hipErrorInvalidValue;
+        const int nblk = gpt_slab_col_blocks(a.H, a.ncols, cus);
+        hipError_t e;
+        if (R > 0) {
+            if (!a.tw_sub || !op_is_lpdf_vjp(op)) return hipErrorInvalidValue;
+            const int HS = a.H / R;
+            e = gpt_long_rowstep(false, R, spec, ld, HS, a.ncols, a.ph.tw, st);
+            if (e != hipSuccess) return e;
+            e = sub_by_size(HS, [&](auto l) { return decltype(l)::colsub(op, a, R, spec, ld, a.tw_sub, partials, nblk, nullptr, 0, st); });
+            if (e != hipSuccess) return e;
+            e = gpt_long_rowstep(true, R, spec, ld, HS, a.ncols, a.ph.tw, st);
+        } else {
+            e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, spec, ld, partials, nblk, nullptr, 0, st); });
+        }
         if (e != hipSuccess) return e;
         return gpt_launch_finalize(partials, nblk, 1, 1, 0.0, a.out_lpdf, a.min_eig, st);
     }

@@ -500,6 +500,29 @@ __global__ void __launch_bounds__(2 * (W / E), 4)
     }
 }
 
+// Plain complex line transform in place (unnormalised): `nlines` contiguous lines of N points. The sub-line
+// transforms of the long-row passes (gpt_long.hip).
+template <int N, bool INV>
+__global__ void __launch_bounds__(Geo<N>::ROW_THREADS) line_fft_kernel(cplx* __restrict__ data, int64_t nlines,
+                                                                       const cplx* __restrict__ tw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = Geo<N>::T, LINES = Geo<N>::ROW_LINES;
+    const int line = threadIdx.x / T, t = threadIdx.x - line * T;
+    double* lds = reinterpret_cast<double*>(smem) + (size_t)line * N;
+    const int64_t l = (int64_t)blockIdx.x * LINES + line;
+    const bool active = l < nlines;
+    cplx* d = data + (active ? l : 0) * N;
+    cplx wpre[tw_npre<N>() > 0 ? tw_npre<N>() : 1];
+    tw_load<N>(wpre, tw, t);
+    cplx v[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) v[m] = d[t + T * m];
+    fft_regs<N, INV>(v, t, lds, wpre);
+    if (!active) return;
+#pragma unroll
+    for (int m = 0; m < E; ++m) d[t + T * m] = v[m];
+}
+
 // Host-side launchers, one specialisation per line length (gpt_sub_n.hip).
 template <int N> struct LaunchSub {
     static hipError_t row_fwd4(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, hipStream_t st);
@@ -510,6 +533,7 @@ template <int N> struct LaunchSub {
                              int nwg, double* edge, int edge_flags, hipStream_t st);
     static int col_tile();
     static int col_blocks(int R, int ncols, int cus);
+    static hipError_t line_fft(bool inverse, cplx* data, int64_t nlines, const cplx* tw, hipStream_t st);
 };
 
 } // namespace pow2

@@ -62,6 +62,18 @@ hipError_t LaunchSub<GPT_N>::row_inv4(const LatArgs&, double, const cplx*, int, 
 }
 #endif
 
+template <>
+hipError_t LaunchSub<GPT_N>::line_fft(bool inverse, cplx* data, int64_t nlines, const cplx* tw, hipStream_t st) {
+    constexpr int N = GPT_N;
+    const size_t lds = (size_t)Geo<N>::ROW_LINES * N * sizeof(double);
+    hipError_t e = inverse ? raise_lds_sub(line_fft_kernel<N, true>, lds) : raise_lds_sub(line_fft_kernel<N, false>, lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)((nlines + Geo<N>::ROW_LINES - 1) / Geo<N>::ROW_LINES));
+    if (inverse) hipLaunchKernelGGL((line_fft_kernel<N, true>), grid, dim3(Geo<N>::ROW_THREADS), lds, st, data, nlines, tw);
+    else hipLaunchKernelGGL((line_fft_kernel<N, false>), grid, dim3(Geo<N>::ROW_THREADS), lds, st, data, nlines, tw);
+    return hipGetLastError();
+}
+
 #if GPT_N <= 4096
 template <int OP>
 static hipError_t colsub_t(const LatArgs& a, int R, cplx* ws, int wstride, const cplx* tws, double* partials, int nwg,

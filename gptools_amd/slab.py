@@ -14,8 +14,8 @@ The local passes are the HIP kernels of the single-GPU path (C ABI `gpt_slab_*`)
 tests plug in their own local passes). `cov` / `d/dcov` keep the lattice's own H x (W/2+1) layout on every
 rank; a rank touches only its columns (and column W/2 on rank 0).
 
-Supported sizes are those of the power-of-two kernels (heights 256..8192, widths 256..16384): the 32768-point line transform of
-config 5 needs a four-step line FFT that is not built yet.
+Supported sizes: power-of-two heights and widths in 256..32768. Lines of more than 8192 (columns) / 16384 (rows)
+points, i.e. config 5's 32768 x 32768, take the four-step route of csrc/gpt_long.hip.
 """
 from __future__ import annotations
 

@@ -97,6 +97,89 @@ def test_slab_headline_shape_eight_ranks():
         np.testing.assert_allclose(oc[:, cols], gc1[:, cols], rtol=RTOL, atol=RTOL * np.abs(gc1).max())
 
 
+@pytest.mark.parametrize("h,w,world", [(32768, 256, 1), (32768, 256, 4), (16384, 512, 2), (256, 32768, 2),
+                                       (512, 32768, 1)])
+def test_slab_long_lines_match_oracle(h, w, world):
+    """Lines of more than 8192 (columns) / 16384 (rows) points take the four-step route of gpt_long.hip: radix-4/8
+    step across rows + sub-line column kernel, radix-8 step + sub-line transforms + split along rows."""
+    test_slab_matches_oracle(h, w, world)
+
+
+def test_slab_config5_32768_eight_ranks():
+    """BASELINE config 5: one 32768 x 32768 lattice over 8 (simulated) ranks. No CPU oracle at this size: the
+    input is loc + a sum of plane waves, for which the spectrum, the log density, d/dy and d/dcov are known in
+    closed form (every wave sits on one interior frequency (a, b): |F|^2 = (A n / 2)^2 there, 0 elsewhere), and
+    the log-determinant part is checked against the elementwise gp_rfft2_log_abs_det_jac kernel."""
+    from gptools_amd import fft, slab
+
+    h = w = 32768
+    world = 8
+    n = h * w
+    dev = torch.device("cuda", 0)
+    rows, nc = slab.slab_shapes(h, w, world)
+    cov = fft.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.3, [8.0, 12.0], [float(h), float(w)]) + 1e-3
+    waves = [(12345, 6789, 0.7), (31111, 15001, 1.3), (1, 16383, 0.4), (20480, 3, 2.0), (7, 8200, 0.9)]
+
+    def wave_rows(rank):
+        i = torch.arange(rank * rows, (rank + 1) * rows, device=dev, dtype=torch.int64)[:, None]
+        j = torch.arange(w, device=dev, dtype=torch.int64)[None, :]
+        tot = torch.zeros(rows, w, dtype=torch.float64, device=dev)
+        dy = torch.zeros(rows, w, dtype=torch.float64, device=dev)
+        for a, b, amp in waves:
+            ph = ((a * i) % h).double() / h + ((b * j) % w).double() / w
+            c = torch.cos(2.0 * np.pi * ph)
+            tot += amp * c
+            dy -= amp / float(cov[a, b]) * c
+        return tot, dy
+
+    out_cov = torch.full((h, w // 2 + 1), float("nan"), dtype=torch.float64, device=dev)
+    shared = slab.ThreadComm.Shared(world)
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(dev)
+            g = torch.Generator(device=dev)
+            g.manual_seed(100 + rank)
+            loc = torch.randn(rows, w, dtype=torch.float64, device=dev, generator=g)
+            wv, dy_want = wave_rows(rank)
+            lp, gy, mn = slab.gp_rfft2_lpdf_vjp_slab(loc + wv, loc, cov, h, w, comm=slab.ThreadComm(shared, rank),
+                                                     out_cov=out_cov)
+            err = float((gy - dy_want).abs().max()) / float(dy_want.abs().max())
+            torch.cuda.synchronize()
+            results[rank] = (float(lp), err, float(mn))
+        except Exception as exc:
+            errors.append(exc)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    if errors:
+        raise errors[0]
+    ladj = float(fft.gp_rfft2_log_abs_det_jac(cov, w))
+    want = -sum(amp * amp * n / (4.0 * float(cov[a, b])) for a, b, amp in waves) - 0.5 * n * np.log(2 * np.pi) + ladj
+    for lp, err, mn in results:
+        np.testing.assert_allclose(lp, want, rtol=1e-9)
+        # y - loc carries the rounding of loc (|loc| ~ 4): its transform is exact to ~1e-16 * sqrt(n) per entry
+        assert err < 1e-8, err
+        np.testing.assert_allclose(mn, 0.5 * n * float(cov.min()), rtol=1e-13)
+    # d/dcov: -1/c on pair entries (half of it on the four real points, 0 on the unread mirror rows of the edge
+    # columns), plus |F|^2 / (n c^2) on the waves' entries
+    want_c = -1.0 / cov
+    want_c[h // 2 + 1:, 0] = 0.0
+    want_c[h // 2 + 1:, w // 2] = 0.0
+    for i0 in (0, h // 2):
+        for j0 in (0, w // 2):
+            want_c[i0, j0] *= 0.5
+    for a, b, amp in waves:
+        want_c[a, b] += amp * amp * n / (4.0 * float(cov[a, b]) ** 2)
+    err_c = float(((out_cov - want_c).abs() / want_c.abs().clamp_min(1e-300)).nan_to_num(nan=1.0).max())
+    assert err_c < 1e-8, err_c
+
+
 def test_slab_rejects_misaligned_columns():
     from gptools_amd import fft
 
@@ -107,8 +190,8 @@ def test_slab_rejects_misaligned_columns():
     lp = torch.zeros(1, dtype=torch.float64, device=dev)
     with pytest.raises(ValueError):  # 6 columns are not a multiple of the 4-column tile of H = 4096
         ctx.call("gpt_slab_cols_lpdf_vjp", fft._p(spec), 6, fft._p(cov), None, 4096, 4096, 0, 6, fft._p(lp), None)
-    with pytest.raises(NotImplementedError):  # 32768-point lines are not built yet
-        ctx.call("gpt_slab_rows_fwd", fft._p(cov), None, 2, 32768, 32768, fft._p(spec), 16384)
+    with pytest.raises(NotImplementedError):  # lines stop at 32768 points
+        ctx.call("gpt_slab_rows_fwd", fft._p(cov), None, 2, 256, 65536, fft._p(spec), 32768)
 
 
 def _dist_worker(rank, world, port, h, w, q):
