@@ -7,7 +7,7 @@ run() {
   python3 - "$tag" <<PY
 import json,sys
 r=json.load(open("gpurun_out/cmp_%s.json"%sys.argv[1]))
-print(sys.argv[1], round(r["value"],1), " ".join("%s=%.1f"%(k["name"].split()[0], 1e3*k["avg_ms_per_eval"]) for k in r["roofline"]["kernels"]), "frac=%.4f"%r["roofline"]["frac"])
+print(sys.argv[1], round(r["value"],1), " ".join("%s=%.1f"%(k["name"].split()[0], 1e3*k["avg_ms_per_eval"]) for k in r["roofline"].get("kernels",[])), "frac=%.4f"%r["roofline"]["frac"])
 PY
 }
 run whole GPT_SUBLINE=0 && run sub2 GPT_SUBLINE=2 && run sub4 GPT_SUBLINE=4
