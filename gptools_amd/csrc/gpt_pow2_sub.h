@@ -224,17 +224,29 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : 2))  // wave
                 v[k][m] = (op_has_fwd(OP) && !skip)
                               ? wsb[(unsigned)(rowq + tl[k] + T * m) * (unsigned)wstride + (unsigned)jl]
                               : make_double2(0.0, 0.0);
+        // GPT_COV_ALL = 2: the cov values of the tile are requested right behind the spectrum loads and arrive,
+        // cold from HBM, while the forward transform runs (1: all at once, but after the transform)
+        double cve[GPT_COV_ALL == 2 ? V : 1][GPT_COV_ALL == 2 ? E : 1];
+        if (GPT_COV_ALL == 2 && NEEDS_COV && !skip) {
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+#pragma unroll
+                for (int m = 0; m < E; ++m)
+                    cve[k][m] = P.cov[(unsigned)(R * (tl[k] + T * m) + q) * (unsigned)L.Wf + (unsigned)jp];
+        }
         if (op_has_fwd(OP)) fft_regs<HS, false, V, 0>(v, tl, lds, wl);
         if (!skip && !(GPT_ABLATE & 4)) {
             if (GPT_COV_ALL) {
-                // every cov value of the tile is requested before the first one is used: the column pass waits
-                // for HBM here (cold reads in narrow pieces), and one long wait is shorter than V
                 double cv[V][E];
 #pragma unroll
                 for (int k = 0; k < V; ++k)
 #pragma unroll
-                    for (int m = 0; m < E; ++m)
-                        cv[k][m] = NEEDS_COV ? P.cov[(unsigned)(R * (tl[k] + T * m) + q) * (unsigned)L.Wf + (unsigned)jp] : 1.0;
+                    for (int m = 0; m < E; ++m) {
+                        if (GPT_COV_ALL == 2)
+                            cv[k][m] = NEEDS_COV ? cve[k][m] : 1.0;
+                        else
+                            cv[k][m] = NEEDS_COV ? P.cov[(unsigned)(R * (tl[k] + T * m) + q) * (unsigned)L.Wf + (unsigned)jp] : 1.0;
+                    }
                 SCHED_FENCE();
 #pragma unroll
                 for (int k = 0; k < V; ++k)

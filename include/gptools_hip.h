@@ -77,7 +77,8 @@ int gpt_path_for_shape(int64_t height, int64_t width);
  * Rank g owns `rows` consecutive rows of y, loc and d/dy (row slab) and `ncols` consecutive PACKED columns of
  * the half spectrum (column slab; packed column j holds frequency j, column 0 holds DC + i * Nyquist). The
  * exchange between the two layouts (an all-to-all over RCCL) belongs to the caller: gptools_amd/slab.py.
- * Device pointers, asynchronous on the context's stream, power-of-two height in [256, 8192] and width in [256, 16384].
+ * Device pointers, asynchronous on the context's stream, power-of-two height and width in [256, 32768] (lines of more
+ * than 8192 / 16384 points take a four-step route inside the same calls and use library-owned scratch).
  *   gpt_slab_rows_fwd:      spec[rows][ld] complex <- packed real FFT along the width of (y - loc)[rows][W]
  *   gpt_slab_cols_lpdf_vjp: on spec[H][ld] (all rows of columns col0 .. col0+ncols-1), in place: column FFT,
  *                           log-density terms of fft2.stan:189-192 and F/c, inverse column FFT. cov and

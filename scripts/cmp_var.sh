@@ -8,6 +8,6 @@ for f in gptools_amd/libgptools_hip.so gptools_amd/libvar_*.so; do
   python3 - "$tag" <<PY
 import json,sys
 r=json.load(open("gpurun_out/var_%s.json"%sys.argv[1]))
-print(sys.argv[1], round(r["value"],1), " ".join("%s=%.1f"%(k["name"].split()[0], 1e3*k["avg_ms_per_eval"]) for k in r["roofline"]["kernels"]))
+print(sys.argv[1], round(r["value"],1), " ".join("%s=%.1f"%(k["name"].split()[0], 1e3*k["avg_ms_per_eval"]) for k in r["roofline"].get("kernels", [])))
 PY
 done
