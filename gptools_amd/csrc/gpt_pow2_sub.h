@@ -25,6 +25,9 @@ namespace pow2 {
 #ifndef GPT_SUB_WPS1
 #define GPT_SUB_WPS1 4
 #endif
+#ifndef GPT_TOUCH
+#define GPT_TOUCH 0
+#endif
 #ifndef GPT_STAGGER
 #define GPT_STAGGER 0
 #endif
@@ -234,7 +237,25 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : 2))  // wave
                 for (int m = 0; m < E; ++m)
                     cve[k][m] = P.cov[(unsigned)(R * (tl[k] + T * m) + q) * (unsigned)L.Wf + (unsigned)jp];
         }
+#if GPT_TOUCH
+        // One dword of every cov row piece of the tile, requested behind the spectrum loads: the lines travel from
+        // HBM while the forward transform runs and the elementwise stage finds them on-die.
+        constexpr int NT = HS / THREADS;
+        int touch[NT];
+        if (NEEDS_COV) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                touch[u] = *reinterpret_cast<const int*>(
+                    P.cov + (unsigned)(R * ((int)threadIdx.x + THREADS * u) + q) * (unsigned)L.Wf + (unsigned)(a.col0 + j0));
+        }
+#endif
         if (op_has_fwd(OP)) fft_regs<HS, false, V, 0>(v, tl, lds, wl);
+#if GPT_TOUCH
+        if (NEEDS_COV) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u) asm volatile("" ::"v"(touch[u]));
+        }
+#endif
         if (!skip && !(GPT_ABLATE & 4)) {
             if (GPT_COV_ALL) {
                 double cv[V][E];
