@@ -345,3 +345,45 @@ def test_headline_shape_4096(fft):
     # the gradient w.r.t. y is linear in (y - loc): grad(loc + 2 (y - loc)) == 2 grad(y)
     _, gy2, _ = fft.gp_rfft2_lpdf_vjp(loc_d + 2.0 * (y_d - loc_d), loc_d, cov_d, need_cov_grad=False)
     close(gy2, 2.0 * gy.cpu().numpy(), rtol=1e-9)
+
+
+def test_subline_path_variants(fft):
+    """The sub-line kernels (fused value + gradient at heights >= 512) with everything the plain cases leave out:
+    a spectrum per lattice, no loc, no d/dcov, more lattices than one workspace chunk holds, and the reject of a
+    negative spectrum entry in a row above H/2 of an edge column (never read by the transform, still checked)."""
+    h, w = 1024, 2048
+    b = 5
+    rng = np.random.default_rng(77)
+    y = rng.normal(size=(b, h, w))
+    loc = rng.normal(size=(h, w))
+    base = o.gp_periodic_matern_cov_rfft2(2.5, h, w, 0.9, [h / 50.0, w / 35.0], [float(h), float(w)]) + 1e-3
+    cov = base * np.exp(0.1 * rng.normal(size=(b,) + base.shape))
+    lp, gy, gc = fft.gp_rfft2_lpdf_vjp(y, loc, cov)
+    for i in range(b):
+        lp_o, gy_o, gc_o = o.gp_rfft2_lpdf_vjp(y[i], loc, cov[i])
+        close(lp[i], lp_o)
+        close(gy[i], gy_o)
+        close(gc[i], gc_o)
+    lp2, gy2, gc2 = fft.gp_rfft2_lpdf_vjp(y, None, cov, need_cov_grad=False)
+    assert gc2 is None
+    lp_o, gy_o, _ = o.gp_rfft2_lpdf_vjp(y[b - 1], np.zeros((h, w)), cov[b - 1])
+    close(lp2[b - 1], lp_o)
+    close(gy2[b - 1], gy_o)
+    # 40 lattices of 2048 x 1024 (16 MiB of packed spectrum each): several workspace chunks
+    h2, w2 = 2048, 1024
+    y2 = rng.normal(size=(40, h2, w2))
+    cov2 = o.gp_periodic_matern_cov_rfft2(1.5, h2, w2, 1.1, [20.0, 15.0], [float(h2), float(w2)]) + 1e-3
+    lp3, gy3, gc3 = fft.gp_rfft2_lpdf_vjp(y2, None, cov2)
+    for i in (0, 7, 39):
+        lp_o, gy_o, gc_o = o.gp_rfft2_lpdf_vjp(y2[i], np.zeros((h2, w2)), cov2)
+        close(lp3[i], lp_o)
+        close(gy3[i], gy_o)
+        close(gc3[i], gc_o)
+    bad = cov.copy()
+    bad[3, h - 2, 0] = -1.0
+    with pytest.raises(ValueError, match="not positive-definite"):
+        fft.gp_rfft2_lpdf_vjp(y, loc, bad)
+    bad = cov.copy()
+    bad[1, 5, 77] = -2.0
+    with pytest.raises(ValueError, match="not positive-definite"):
+        fft.gp_rfft2_lpdf_vjp(y, loc, bad)
