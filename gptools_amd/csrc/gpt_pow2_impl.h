@@ -46,7 +46,10 @@ __device__ unsigned long long g_col_trace[1024 * 8 * 8];
 
 namespace pow2 {
 
-constexpr int E = 16;
+#ifndef GPT_E
+#define GPT_E 16
+#endif
+constexpr int E = GPT_E; // elements of a register tile (= the largest butterfly radix)
 #ifndef GPT_COL_WGS_PER_CU
 #define GPT_COL_WGS_PER_CU 1
 #endif
@@ -196,9 +199,9 @@ template <bool INV> struct Bfly<16, INV> {
 // a multiple of 4) comes FIRST, where NS = 1 means no twiddles at all; every later stage is a radix-16 stage
 // with one twiddle base per register tile.
 constexpr int stage_radix(int n, int ns) {
-    if (ns > 1) return 16;
+    if (ns > 1) return E;
     int r = n;
-    while (r > 16) r /= 16;
+    while (r > E) r /= E;
     return r;
 }
 template <int N> constexpr int tw_npre() {

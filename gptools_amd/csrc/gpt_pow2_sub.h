@@ -22,6 +22,12 @@
 
 namespace pow2 {
 
+#ifndef GPT_CVN
+#define GPT_CVN 0
+#endif
+#ifndef GPT_SUB_WPS2
+#define GPT_SUB_WPS2 2
+#endif
 #ifndef GPT_SUB_WPS1
 #define GPT_SUB_WPS1 4
 #endif
@@ -145,7 +151,7 @@ __device__ __forceinline__ void col0_role(const LatArgs& a, const ZLayout& L, co
 // Tiles: (sub-line q, TC adjacent packed columns), ntq column tiles per sub-line; tile = q * ntq + ct.
 // Same persistent walk and XCD-aware order as col_kernel.
 template <int HS, int V, int THREADS, int OP>
-__global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : 2))  // waves per SIMD the register budget must allow
+__global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2))  // waves per SIMD the register budget must allow
     colsub_kernel(LatArgs a, int R, cplx* __restrict__ ws, int wstride, const cplx* __restrict__ tws,
                   double* __restrict__ partials, int ntq, double* __restrict__ edge, int edge_flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -156,7 +162,7 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : 2))  // wave
     // timing-only experiments (GPT_EXP bits; results wrong): 1 = no d/dcov stores, 2 = no cov loads, 4 = cov and
     // d/dcov rows addressed with an aligned stride (Wf - 1), 8 = cov read from 64 rows only (cache hits)
     constexpr int EWOP = (GPT_EXP & 1) && OP == OP_LPDF_VJP ? (int)OP_LPDF_VJP_NOCOV : OP;
-    constexpr int CVN = V == 1 ? 8 : E; // cov values requested together (register budget of the 128-VGPR build)
+    constexpr int CVN = GPT_CVN ? GPT_CVN : (V == 1 ? 8 : E); // cov values requested together (register budget of the 128-VGPR build)
     const int c = threadIdx.x % TC, tp = threadIdx.x / TC;
     double* lds = reinterpret_cast<double*>(smem) + (size_t)c * (HS + G::SKEW);
     double* red = reinterpret_cast<double*>(smem);

@@ -23,6 +23,10 @@ constexpr int SUB_V = GPT_SUB_V;
 #define GPT_SUB_T2048 256
 #endif
 constexpr int SUB_THREADS = GPT_N >= 4096 ? 512 : (GPT_N == 2048 ? GPT_SUB_T2048 : 256);
+#ifndef GPT_SUB_WGS_PER_CU
+#define GPT_SUB_WGS_PER_CU (SUB_THREADS == 256 ? 2 : 1)
+#endif
+constexpr int SUB_WGS_PER_CU = GPT_SUB_WGS_PER_CU; // workgroups the register / LDS budget lets share a CU
 using GS = GeoS<GPT_N, SUB_V, SUB_THREADS>;
 } // namespace
 
@@ -102,7 +106,7 @@ hipError_t LaunchSub<GPT_N>::colsub(int op, const LatArgs& a, int R, cplx* ws, i
 template <> int LaunchSub<GPT_N>::col_tile() { return GS::TC; }
 template <> int LaunchSub<GPT_N>::col_blocks(int R, int ncols, int cus) {
     const int ntiles = R * (ncols / GS::TC);
-    int cap = cus * (SUB_THREADS == 256 ? 2 : 1);
+    int cap = cus * SUB_WGS_PER_CU;
     if (cap >= 8) cap &= ~7;
     if (cap < R / 2 + 1) cap = R / 2 + 1; // the packed column 0 needs its R/2 + 1 workgroups
     return ntiles < cap ? (ntiles > R / 2 + 1 ? ntiles : R / 2 + 1) : cap;
