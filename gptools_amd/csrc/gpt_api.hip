@@ -188,7 +188,13 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
             HIP_TRY(c, gpt_launch_generic(op, s, c->ws, c->partials, c->stream));
             continue;
         }
+        // GPT_DEBUG_PASSES=<bitmask> (timing experiments only: wrong results): run only the passes whose bit is set
+        static const int pass_mask = [] {
+            const char* e = getenv("GPT_DEBUG_PASSES");
+            return e ? atoi(e) : 7;
+        }();
         for (int pass = 0; pass < 3; ++pass) {
+            if (!((pass_mask >> pass) & 1)) continue;
             // each pass bracketed by timing events in profiling mode
             const bool present = pass == 1 || (pass == 0 ? op_has_fwd(op) : op_has_inv(op));
             gpt_ctx::ProfRec pr = {nullptr, nullptr, pass == 2 ? 3 : pass};

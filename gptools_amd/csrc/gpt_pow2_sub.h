@@ -31,6 +31,9 @@ namespace pow2 {
 #ifndef GPT_SUB_WPS1
 #define GPT_SUB_WPS1 4
 #endif
+#ifndef GPT_PRIO
+#define GPT_PRIO 1
+#endif
 #ifndef GPT_TOUCH
 #define GPT_TOUCH 0
 #endif
@@ -39,6 +42,9 @@ namespace pow2 {
 #endif
 #ifndef GPT_COV_ALL
 #define GPT_COV_ALL 0
+#endif
+#ifndef GPT_EXP_DW
+#define GPT_EXP_DW 1
 #endif
 #ifndef GPT_EXP
 #define GPT_EXP 0
@@ -170,7 +176,7 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
     const int H = a.H;
     const ZLayout L = make_layout(a);
     ZLayout LE = L;
-    if (GPT_EXP & 4) LE.Wf -= 1;
+    if (GPT_EXP & 4) LE.Wf -= GPT_EXP_DW;
     EwPtrs P = make_ptrs(a, b);
     if (edge) {
         if (edge_flags & 1) P.edge_cov = edge + b * 4 * (int64_t)H;
@@ -226,6 +232,13 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
 #pragma unroll
         for (int k = 0; k < V; ++k) tw_load<HS>(wl[k], tws, tl[k]);
         cplx v[V][E];
+#if GPT_PRIO
+        // The two workgroups of a CU do not get equal shares (the older waves win the arbitration: the first half
+        // of the grid ends 25 us before the second): they take turns at the higher wave priority, tile by tile.
+        if ((r + (2 * blockIdx.x >= gridDim.x ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(GPT_PRIO);
+        else __builtin_amdgcn_s_setprio(0);
+#endif
+        TRACE_MARK(r, 0);
 #pragma unroll
         for (int k = 0; k < V; ++k)
 #pragma unroll
@@ -233,6 +246,11 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
                 v[k][m] = (op_has_fwd(OP) && !skip)
                               ? wsb[(unsigned)(rowq + tl[k] + T * m) * (unsigned)wstride + (unsigned)jl]
                               : make_double2(0.0, 0.0);
+#if GPT_TRACE
+        TRACE_MARK(r, 1); // loads issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TRACE_MARK(r, 2); // ... and arrived
+#endif
         // GPT_COV_ALL = 2: the cov values of the tile are requested right behind the spectrum loads and arrive,
         // cold from HBM, while the forward transform runs (1: all at once, but after the transform)
         double cve[GPT_COV_ALL == 2 ? V : 1][GPT_COV_ALL == 2 ? E : 1];
@@ -262,6 +280,7 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
             for (int u = 0; u < NT; ++u) asm volatile("" ::"v"(touch[u]));
         }
 #endif
+        TRACE_MARK(r, 3); // forward transform done
         if (!skip && !(GPT_ABLATE & 4)) {
             if (GPT_COV_ALL) {
                 double cv[V][E];
@@ -306,6 +325,11 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
         }
         acc_fold(acc);
         __builtin_amdgcn_sched_barrier(0);
+#if GPT_TRACE
+        TRACE_MARK(r, 4); // elementwise stage issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TRACE_MARK(r, 5); // ... and its stores retired
+#endif
         if (op_has_inv(OP) && !(GPT_ABLATE & 8)) {
             int t_inv[V];
 #pragma unroll
@@ -316,6 +340,7 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
                 for (int i = 0; i < NPRE; ++i) asm volatile("" : "+v"(wl[k][i].x), "+v"(wl[k][i].y), "+v"(v[0][0].x));
             }
             fft_regs<HS, true, V, 0>(v, t_inv, lds, wl);
+            TRACE_MARK(r, 6); // inverse transform done
             if (!skip) {
 #pragma unroll
                 for (int k = 0; k < V; ++k)
@@ -323,6 +348,7 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
                     for (int m = 0; m < E; ++m)
                         wsb[(unsigned)(rowq + t_inv[k] + T * m) * (unsigned)wstride + (unsigned)jl] = v[k][m];
             }
+            TRACE_MARK(r, 7);
         }
     }
     if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {

@@ -122,3 +122,12 @@ template <> int LaunchSub<GPT_N>::col_blocks(int, int, int) { return 0; }
 #endif
 
 } // namespace pow2
+
+#if GPT_TRACE
+// debug builds only: copy the column kernel's phase timestamps to the host (scripts/trace_sub.py)
+extern "C" int gpt_debug_sub_trace(unsigned long long* dst, size_t n) {
+    if (n > sizeof(g_col_trace) / sizeof(g_col_trace[0])) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_col_trace), n * sizeof(unsigned long long));
+}
+#endif
