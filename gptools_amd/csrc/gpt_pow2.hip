@@ -45,12 +45,10 @@ int sub_choice() {
 // two-halves row kernels and whose columns split into four sub-lines of 256..2048 points.
 int gpt_pow2_sub_radix(int op, int H, int W) {
     const int r = sub_choice();
-    if (r == 0 || !op_is_lpdf_vjp(op) || !gpt_pow2_supported(H, W)) return 0;
-    if (r == 4) {
-        if (!(W == 1024 || W == 2048 || W == 4096)) return 0;
-        return (H >= 1024 && H <= 8192) ? 4 : 0;
-    }
-    return (H >= 512 && H <= 8192) ? 2 : 0; // sub-lines of 256..4096 points, any row length
+    if (r == 0 || op < 0 || op >= OP_COUNT || !gpt_pow2_supported(H, W)) return 0;
+    if (r == 4 && op_is_lpdf_vjp(op) && (W == 1024 || W == 2048 || W == 4096) && H >= 1024 && H <= 8192)
+        return 4; // experiment: fused value + gradient only
+    return (H >= 512 && H <= 8192) ? 2 : 0; // sub-lines of 256..4096 points, any row length, every op
 }
 static int sub_col_blocks(int R, int H, int W, int cus) {
     int nb = 1;
@@ -83,7 +81,7 @@ static int whole_col_blocks(int H, int W, int cus) {
 // upper bound over the kernels a lattice of this shape may run (sizes the partials buffer)
 int gpt_pow2_col_blocks(int H, int W, int cus) {
     int nb = whole_col_blocks(H, W, cus);
-    if (const int R = gpt_pow2_sub_radix(OP_LPDF_VJP, H, W)) {
+    if (const int R = gpt_pow2_sub_radix(OP_LPDF_VJP, H, W)) { // (the widest grid of the variants)
         const int ns = sub_col_blocks(R, H, W, cus);
         if (ns > nb) nb = ns;
     }
@@ -105,32 +103,22 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
     // for the fused log-density gradient
     double* edge = reinterpret_cast<double*>(ws + (size_t)a.batch * ws_spec_elems(a.H, a.W));
     const int edge_flags = ((op_has_fwd(op) && a.cov) ? 1 : 0) | ((op == OP_LPDF_VJP && a.out_cov) ? 2 : 0);
-    if (sub) {
-        if (pass == 0) {
-            if (R == 2)
-                return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, 1, ws, wstride, (edge_flags & 1) ? edge : nullptr, true, st); });
-            return sub_by_size(a.W, [&](auto l) { return decltype(l)::row_fwd4(a, 1, ws, wstride, (edge_flags & 1) ? edge : nullptr, st); });
-        }
-        if (pass == 1)
-            return sub_by_size(a.H / R, [&](auto l) {
-                return decltype(l)::colsub(op, a, R, ws, wstride, a.tw_sub, partials, nblk,
-                                           edge_flags ? edge : nullptr, edge_flags, st);
-            });
-        if (pass == 2) {
-            const FinArgs fin = {partials, nblk, add, a.out_lpdf, a.min_eig};
-            if (R == 2)
-                return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, -1.0 / n, 0, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, true, st); });
-            return sub_by_size(a.W, [&](auto l) { return decltype(l)::row_inv4(a, -1.0 / n, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, st); });
-        }
-        return hipErrorInvalidValue;
-    }
     if (pass == 0) {
         if (!op_has_fwd(op)) return hipSuccess;
         const int in_mode = op == OP_RFFT2 ? 0 : (op == OP_INV_VJP ? 2 : 1);
-        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, in_mode, ws, wstride, (edge_flags & 1) ? edge : nullptr, false, st); });
+        if (R == 4)
+            return sub_by_size(a.W, [&](auto l) { return decltype(l)::row_fwd4(a, in_mode, ws, wstride, (edge_flags & 1) ? edge : nullptr, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, in_mode, ws, wstride, (edge_flags & 1) ? edge : nullptr, R == 2, st); });
     }
     if (pass == 1) {
-        hipError_t e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, ws, wstride, partials, nblk, edge_flags ? edge : nullptr, edge_flags, st); });
+        hipError_t e;
+        if (sub)
+            e = sub_by_size(a.H / R, [&](auto l) {
+                return decltype(l)::colsub(op, a, R, ws, wstride, a.tw_sub, partials, nblk,
+                                           edge_flags ? edge : nullptr, edge_flags, st);
+            });
+        else
+            e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, ws, wstride, partials, nblk, edge_flags ? edge : nullptr, edge_flags, st); });
         if (e != hipSuccess) return e;
         // second reduction stage: folded into pass C when there is one
         if (reduces && !op_has_inv(op))
@@ -152,7 +140,9 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
         if (op == OP_INV_RFFT2) alpha = 1.0 / n;
         else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
         else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
-        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, false, st); });
+        if (R == 4)
+            return sub_by_size(a.W, [&](auto l) { return decltype(l)::row_inv4(a, alpha, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, R == 2, st); });
     }
     return hipErrorInvalidValue;
 }

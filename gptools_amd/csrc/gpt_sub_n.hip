@@ -97,7 +97,14 @@ template <>
 hipError_t LaunchSub<GPT_N>::colsub(int op, const LatArgs& a, int R, cplx* ws, int wstride, const cplx* tws,
                                     double* partials, int nwg, double* edge, int edge_flags, hipStream_t st) {
     switch (op) {
+    case OP_RFFT2: return colsub_t<OP_RFFT2>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    case OP_INV_RFFT2: return colsub_t<OP_INV_RFFT2>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    case OP_GP_RFFT2: return colsub_t<OP_GP_RFFT2>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    case OP_GP_INV_RFFT2: return colsub_t<OP_GP_INV_RFFT2>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    case OP_LPDF: return colsub_t<OP_LPDF>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
     case OP_LPDF_VJP: return colsub_t<OP_LPDF_VJP>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    case OP_INV_VJP: return colsub_t<OP_INV_VJP>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    case OP_FWD_VJP: return colsub_t<OP_FWD_VJP>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
     case OP_LPDF_VJP_NOCOV:
         return colsub_t<OP_LPDF_VJP_NOCOV>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
     default: return hipErrorInvalidValue;
