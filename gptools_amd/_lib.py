@@ -73,6 +73,14 @@ _PLAIN = {
     "gpt_profile_begin": ([c_ptr], c_int),
     "gpt_profile_end": ([c_ptr, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)], c_int),
     "gpt_path_for_shape": ([c_i64, c_i64], c_int),
+    # cross-chain batching
+    "gpt_batcher_create": ([c_int, c_int, c_int, c_i64, c_i64, c_int, ctypes.POINTER(c_ptr)], c_int),
+    "gpt_batcher_destroy": ([c_ptr], c_int),
+    "gpt_batcher_lpdf_host": ([c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr], c_int),
+    "gpt_batcher_leave": ([c_ptr, c_int], c_int),
+    "gpt_batcher_min_eig": ([c_ptr, c_int], c_dbl),
+    "gpt_batcher_launches": ([c_ptr], ctypes.c_longlong),
+    "gpt_batcher_last_error": ([c_ptr], ctypes.c_char_p),
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_PLAIN))

@@ -96,6 +96,27 @@ int gpt_slab_cols_lpdf_vjp(gpt_ctx*, double* spec, int64_t ld, const double* cov
 int gpt_slab_rows_inv(gpt_ctx*, const double* spec, int64_t ld, int64_t rows, int64_t height, int64_t width,
                       double alpha, double* out);
 
+/* ---- cross-chain batching (no counterpart in the reference, where every chain evaluates
+ * gp_rfft(2)_lpdf on its own CPU core) ---------------------------------------------------------------------
+ * The chains of ONE process (cmdstan threads under STAN_THREADS, or any threads) share a batcher and own one
+ * slot each. gpt_batcher_lpdf_host is gpt_gp_rfft2_lpdf_host for the calling chain's lattice (host pointers,
+ * the batcher's `layout`; loc may be NULL; grad_y NULL: value only; grad_cov may be NULL), but it BLOCKS until
+ * every active slot has called, and the last arrival evaluates all slots in ONE fused launch. Return value as
+ * for the host entry points, per chain: GPT_ERR_NOT_PD concerns the calling chain's spectrum only
+ * (gpt_batcher_min_eig has the value). A chain that stops calling (sampling finished, exception) must
+ * gpt_batcher_leave its slot, or the others wait for it forever. Thread-safe by construction; one batcher per
+ * lattice shape. */
+typedef struct gpt_batcher gpt_batcher;
+int gpt_batcher_create(int device, int nslots, int layout, int64_t height, int64_t width, int dim1,
+                       gpt_batcher** out);
+int gpt_batcher_destroy(gpt_batcher* b);
+int gpt_batcher_lpdf_host(gpt_batcher* b, int slot, const double* y, const double* loc, const double* cov,
+                          double* lpdf, double* grad_y, double* grad_cov);
+int gpt_batcher_leave(gpt_batcher* b, int slot);
+double gpt_batcher_min_eig(gpt_batcher* b, int slot);
+long long gpt_batcher_launches(gpt_batcher* b); /* fused launches so far */
+const char* gpt_batcher_last_error(gpt_batcher* b);
+
 /* ---- real-FFT layer: stan/gptools/util.stan:255-330 ------------------------------------------------ */
 /* rfft2 (util.stan:302-304): y[batch][H][W] -> out[batch][H][W/2+1] complex.  rfft (util.stan:263-265) is
  * the height == 1 case. */
