@@ -29,18 +29,22 @@ enum GptOp : int {
     OP_INV_VJP = 6,      // VJP of OP_GP_INV_RFFT2: fbar -> zbar, covbar
     OP_FWD_VJP = 7,      // VJP of OP_GP_RFFT2: zbar -> ybar, covbar
     OP_LPDF_VJP_NOCOV = 8, // OP_LPDF_VJP without d/dcov (caller passed grad_cov == NULL)
-    OP_COUNT = 9
+    OP_LPDF_KVJP = 9,    // OP_LPDF_VJP with the spectrum evaluated on the fly from kernel parameters
+                         // (fft2.stan:206-247 + nugget) and d/dcov contracted into d/d(sigma, length_scale, period)
+    OP_COUNT = 10
 };
 
-__host__ __device__ constexpr bool op_is_lpdf_vjp(int op) { return op == OP_LPDF_VJP || op == OP_LPDF_VJP_NOCOV; }
+__host__ __device__ constexpr bool op_is_lpdf_vjp(int op) {
+    return op == OP_LPDF_VJP || op == OP_LPDF_VJP_NOCOV || op == OP_LPDF_KVJP;
+}
 
 __host__ __device__ constexpr bool op_has_fwd(int op) {
     return op == OP_RFFT2 || op == OP_GP_RFFT2 || op == OP_LPDF || op == OP_LPDF_VJP ||
-           op == OP_INV_VJP || op == OP_FWD_VJP || op == OP_LPDF_VJP_NOCOV;
+           op == OP_INV_VJP || op == OP_FWD_VJP || op == OP_LPDF_VJP_NOCOV || op == OP_LPDF_KVJP;
 }
 __host__ __device__ constexpr bool op_has_inv(int op) {
     return op == OP_INV_RFFT2 || op == OP_GP_INV_RFFT2 || op == OP_LPDF_VJP || op == OP_FWD_VJP ||
-           op == OP_LPDF_VJP_NOCOV;
+           op == OP_LPDF_VJP_NOCOV || op == OP_LPDF_KVJP;
 }
 
 // One line-FFT plan (any length): Stockham stages with radices r[0..ns).
@@ -73,6 +77,14 @@ struct LatArgs {
     // col0 .. col0 + ncols - 1 of the lattice; the spectrum buffer holds just those, cov / out_cov keep the
     // lattice's own H x Wf layout. ncols == 0: the whole lattice.
     int col0, ncols;
+    // OP_LPDF_KVJP: the spectrum is c(i, j) = kernel(i, j; kpar[b]) + knugget (fft2.stan:206-247), never stored.
+    // kpar: [batch][5] = (sigma, length_scale[0], length_scale[1], period[0], period[1]); kmatern: 0 = periodic
+    // squared exponential, 1 = Matern with smoothness knu (kgamma = tgamma(knu + 1) / tgamma(knu)).
+    const double* kpar;
+    int kmatern;
+    double knu, kgamma, knugget;
+    double* ksums; // [batch][4]: log density, then the three sums of acc_kern (gpt_launch_kvjp_combine turns them
+                   // into d/d(sigma, length_scale, period))
     // Twiddle table w_{H/4}^m of the sub-line column kernels (gpt_pow2_sub.h); null: whole-column kernels only.
     const cplx* tw_sub;
 };
@@ -199,6 +211,9 @@ struct EwAcc {
     double mn;   // min of n*c/2 seen
     double mant; // sum over pair entries of log(c) is kept as log(mant) + ex * ln 2: one frexp and one
     int ex;      // multiplication per entry instead of a 60-instruction fp64 log (and more accurate)
+    // OP_LPDF_KVJP: sums of cbar * ck, cbar * ck * f1, cbar * ck * f2 (ck = kernel part of c, f = its logarithmic
+    // length-scale sensitivities, kern_eval): everything d/d(sigma, length_scale, period) needs
+    double k0, k1, k2;
 };
 
 __device__ __forceinline__ void acc_init(EwAcc& acc) {
@@ -206,6 +221,7 @@ __device__ __forceinline__ void acc_init(EwAcc& acc) {
     acc.mn = INFINITY;
     acc.mant = 1.0;
     acc.ex = 0;
+    acc.k0 = acc.k1 = acc.k2 = 0.0;
 }
 // acc += log(c) for a pair entry, deferred.
 __device__ __forceinline__ void acc_log(EwAcc& acc, double c) {
@@ -240,6 +256,7 @@ struct EwPtrs {
     // into out_cov by a later pass). Null: the elementwise stage reads cov / writes out_cov itself.
     const double* edge_cov;
     double* edge_dcov;
+    const double* kpar; // OP_LPDF_KVJP: this lattice's kernel parameters
 };
 
 __device__ __forceinline__ EwPtrs make_ptrs(const LatArgs& a, int64_t b) {
@@ -254,7 +271,53 @@ __device__ __forceinline__ EwPtrs make_ptrs(const LatArgs& a, int64_t b) {
     P.out_c = a.out_c ? a.out_c + b * hwf : nullptr;
     P.edge_cov = nullptr;
     P.edge_dcov = nullptr;
+    P.kpar = a.kpar ? a.kpar + b * 5 : nullptr;
     return P;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Spectral density at (i, j) of the half spectrum WITHOUT the nugget (fft2.stan:206-213 exp-quad, :228-247
+// Matern; rows mirrored, k_i = min(i, H - i)) and its sensitivities: d ck / d l1 = ck (1 - f1) / l1,
+// d ck / d p1 = ck (f1 - 1) / p1 (same with f2 for the second axis), d ck / d sigma = 2 ck / sigma.
+struct KernVal {
+    double ck, f1, f2;
+};
+__device__ __forceinline__ KernVal kern_eval(const LatArgs& a, const double* par, int i, int j) {
+    constexpr double PI_ = 3.14159265358979323846;
+    const double sigma = par[0], l1 = par[1], l2 = par[2], p1 = par[3], p2 = par[4];
+    const int ki = (i <= a.H / 2) ? i : a.H - i;
+    const double a1 = (double)ki * l1 / p1, a2 = (double)j * l2 / p2;
+    const double s1 = a1 * a1, s2 = a2 * a2;
+    const double amp = sigma * sigma * (double)a.H * (double)a.W * (l1 / p1) * (l2 / p2);
+    KernVal v;
+    if (!a.kmatern) {
+        v.ck = amp * (2.0 * PI_) * exp(-2.0 * PI_ * PI_ * (s1 + s2));
+        v.f1 = 4.0 * PI_ * PI_ * s1;
+        v.f2 = 4.0 * PI_ * PI_ * s2;
+        return v;
+    }
+    const double arg = 1.0 + 2.0 / a.knu * PI_ * PI_ * (s1 + s2);
+    const double inv = 1.0 / arg;
+    // arg^-(nu + 1): half-integer smoothness (the reference's Python mirror allows nothing else, kernels.py:306)
+    // needs a square root and a few products; anything else the general power
+    double pw;
+    const double twonu = 2.0 * a.knu;
+    if (twonu == 3.0) pw = inv * inv * sqrt(inv);
+    else if (twonu == 5.0) pw = inv * inv * inv * sqrt(inv);
+    else if (twonu == 1.0) pw = inv * sqrt(inv);
+    else pw = pow(arg, -(a.knu + 1.0));
+    v.ck = amp * 4.0 * (PI_ / (2.0 * a.knu)) * a.kgamma * pw;
+    const double g = (a.knu + 1.0) * (4.0 * PI_ * PI_ / a.knu) * inv;
+    v.f1 = g * s1;
+    v.f2 = g * s2;
+    return v;
+}
+// cbar = d lpdf / d c at one entry -> the three sums
+__device__ __forceinline__ void acc_kern(EwAcc& acc, const KernVal& kv, double cbar) {
+    const double w = cbar * kv.ck;
+    acc.k0 += w;
+    acc.k1 = fma(w, kv.f1, acc.k1);
+    acc.k2 = fma(w, kv.f2, acc.k2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -275,6 +338,11 @@ __device__ __forceinline__ cplx ew_interior_c(const LatArgs& a, const ZLayout& L
     if (OP == OP_INV_RFFT2) {
         return P.cin[ic];
     }
+    KernVal kv = {0.0, 0.0, 0.0};
+    if (OP == OP_LPDF_KVJP) { // `c` is not an input: the kernel is evaluated here
+        kv = kern_eval(a, P.kpar, i, j);
+        c = kv.ck + a.knugget;
+    }
     acc.mn = fmin(acc.mn, 0.5 * n * c);
     if (OP == OP_GP_RFFT2) {
         const double inv_s = 1.0 / sqrt(0.5 * n * c);
@@ -292,6 +360,7 @@ __device__ __forceinline__ cplx ew_interior_c(const LatArgs& a, const ZLayout& L
         acc_log(acc, c);
         if (op_is_lpdf_vjp(OP)) {
             if (OP == OP_LPDF_VJP) P.out_cov[ic] = (q - 1.0) * inv_c;
+            if (OP == OP_LPDF_KVJP) acc_kern(acc, kv, (q - 1.0) * inv_c);
             ret = cscale(F, inv_c);
         }
     } else if (OP == OP_INV_VJP) {
@@ -318,7 +387,7 @@ template <int OP>
 __device__ __forceinline__ cplx ew_interior(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int i, int j,
                                            cplx F, EwAcc& acc) {
     double c = 1.0;
-    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) c = P.cov[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && OP != OP_LPDF_KVJP) c = P.cov[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
     return ew_interior_c<OP>(a, L, P, i, j, F, c, acc);
 }
 
@@ -353,6 +422,11 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
         const cplx v = P.cin[cm_];
         return make_double2(0.5 * (u.x + v.x), 0.5 * (u.y - v.y));
     }
+    KernVal kv = {0.0, 0.0, 0.0};
+    if (OP == OP_LPDF_KVJP) { // rows are mirrored in the kernel: the mirror row has the same value
+        kv = kern_eval(a, P.kpar, k, j);
+        c = cm = kv.ck + a.knugget;
+    }
     if (real_pt) cm = c;
     acc.mn = fmin(acc.mn, 0.5 * n * fmin(c, cm));
     const int jz = L.edge_col(j);
@@ -385,6 +459,7 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
                     if (P.edge_dcov) P.edge_dcov[(j ? a.H : 0) + k] = 0.5 * (q - 1.0) * inv_c;
                     else P.out_cov[ck] = 0.5 * (q - 1.0) * inv_c;
                 }
+                if (OP == OP_LPDF_KVJP) acc_kern(acc, kv, 0.5 * (q - 1.0) * inv_c);
                 ret = make_double2(FA.x * inv_c, 0.0);
             }
         } else {
@@ -400,6 +475,7 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
                         P.out_cov[cm_] = 0.0;
                     }
                 }
+                if (OP == OP_LPDF_KVJP) acc_kern(acc, kv, (q - 1.0) * inv_c);
                 ret = cscale(FA, inv_c);
             }
         }
@@ -441,7 +517,7 @@ template <int OP>
 __device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k, int j, cplx FA,
                                        EwAcc& acc) {
     double c = 1.0, cm = 1.0;
-    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && OP != OP_LPDF_KVJP) {
         const bool real_pt = (k == 0) || (2 * k == a.H);
         c = P.cov[(unsigned)k * (unsigned)L.Wf + (unsigned)j];
         cm = real_pt ? c : P.cov[(unsigned)(a.H - k) * (unsigned)L.Wf + (unsigned)j];
@@ -456,7 +532,7 @@ struct EdgeCov {
 template <int OP>
 __device__ __forceinline__ EdgeCov load_edge_cov(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k) {
     EdgeCov e = {1.0, 1.0, 1.0, 1.0};
-    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && OP != OP_LPDF_KVJP) {
         const bool real_pt = (k == 0) || (2 * k == a.H);
         if (P.edge_cov) {
             const int km = real_pt ? k : a.H - k;

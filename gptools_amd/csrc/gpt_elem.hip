@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) spec_kernel(ElemArgs e) {
     double* o = e.out + b * tot;
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < tot; w += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(w / Wf), j = (int)(w - (int64_t)i * Wf);
-        o[w] = spec_value<MATERN>(e, par, i, j);
+        o[w] = spec_value<MATERN>(e, par, i, j) + e.nugget;
     }
 }
 
@@ -339,6 +339,30 @@ hipError_t gpt_launch_elem(int op, const ElemArgs& e, double* partials, hipStrea
     case EL_MATERN_VJP: hipLaunchKernelGGL(spec_vjp_kernel<true>, grid, block, 0, st, e, partials); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+__global__ void kvjp_combine_kernel(const double* ksums, const double* params, int64_t batch, double* lpdf,
+                                    double* params_bar) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double* k = ksums + 4 * b;
+    const double* p = params + 5 * b;
+    if (lpdf) lpdf[b] = k[0];
+    if (params_bar) {
+        double* o = params_bar + 5 * b;
+        o[0] = 2.0 * k[1] / p[0];     // sigma
+        o[1] = (k[1] - k[2]) / p[1];  // length_scale[0]
+        o[2] = (k[1] - k[3]) / p[2];  // length_scale[1]
+        o[3] = (k[2] - k[1]) / p[3];  // period[0]
+        o[4] = (k[3] - k[1]) / p[4];  // period[1]
+    }
+}
+hipError_t gpt_launch_kvjp_combine(const double* ksums, const double* params, int64_t batch, double* lpdf,
+                                   double* params_bar, hipStream_t st) {
+    if (batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kvjp_combine_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, ksums, params, batch,
+                       lpdf, params_bar);
     return hipGetLastError();
 }
 

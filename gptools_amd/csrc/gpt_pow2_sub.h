@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
     using G = GeoS<HS, V, THREADS>;
     constexpr int T = G::T, TC = G::TC, TP = G::TP;
     constexpr int NPRE = tw_npre<HS>();
-    constexpr bool NEEDS_COV = (OP != OP_RFFT2 && OP != OP_INV_RFFT2);
+    constexpr bool NEEDS_COV = (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && OP != OP_LPDF_KVJP); // cov is LOADED
     // timing-only experiments (GPT_EXP bits; results wrong): 1 = no d/dcov stores, 2 = no cov loads, 4 = cov and
     // d/dcov rows addressed with an aligned stride (Wf - 1), 8 = cov read from 64 rows only (cache hits)
     constexpr int EWOP = (GPT_EXP & 1) && OP == OP_LPDF_VJP ? (int)OP_LPDF_VJP_NOCOV : OP;
@@ -353,11 +353,24 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
     }
     if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
         double s = acc.sum, mn = acc.mn;
+        double kk[3] = {acc.k0, acc.k1, acc.k2};
+        if (OP == OP_LPDF_KVJP) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { // (block_sum_min below ends with a barrier-protected read by thread 0)
+                double t = kk[i], dummy = 0.0;
+                block_sum_min(t, dummy, red);
+                kk[i] = t;
+                __syncthreads();
+            }
+        }
         block_sum_min(s, mn, red);
         if (threadIdx.x == 0) {
             double* p = partials + ((int64_t)b * gridDim.x + blockIdx.x) * GPT_PART;
             p[0] = s;
-            p[1] = p[2] = p[3] = p[4] = 0.0;
+            p[1] = OP == OP_LPDF_KVJP ? kk[0] : 0.0;
+            p[2] = OP == OP_LPDF_KVJP ? kk[1] : 0.0;
+            p[3] = OP == OP_LPDF_KVJP ? kk[2] : 0.0;
+            p[4] = 0.0;
             p[5] = mn;
         }
     }
