@@ -22,6 +22,8 @@ struct gpt_ctx {
     size_t partials_bytes = 0;
     double* sink = nullptr; // write-only dump for gradients the caller did not ask for
     size_t sink_bytes = 0;
+    double* kscr = nullptr; // kernel-fused log density: per-lattice sums, or the spectrum + d/dcov of the fallback
+    size_t kscr_bytes = 0;
     cplx* ltmp = nullptr; // scratch lines of the long-row passes (gpt_long.hip)
     size_t ltmp_bytes = 0;
     char* arena = nullptr; // device staging arena of the host-pointer entry points
@@ -305,6 +307,7 @@ int gpt_destroy(gpt_ctx* c) {
     if (c->partials) (void)hipFree(c->partials);
     if (c->arena) (void)hipFree(c->arena);
     if (c->ltmp) (void)hipFree(c->ltmp);
+    if (c->kscr) (void)hipFree(c->kscr);
     if (c->sink) (void)hipFree(c->sink);
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
@@ -656,6 +659,75 @@ int gpt_gp_rfft2_vjp(gpt_ctx* c, const double* y, int64_t y_bs, const double* lo
 static double gamma_ratio(double nu, int dim1) {
     const double half_ndim = dim1 ? 0.5 : 1.0;
     return std::tgamma(nu + half_ndim) / std::tgamma(nu); // fft1.stan:173, fft2.stan:245
+}
+
+// Kernel-fused log density: lpdf(y | loc, kernel(params) + nugget) with the reverse mode down
+// to the kernel parameters. Power-of-two lattices of 512..8192 rows evaluate the spectrum inside the column pass
+// (OP_LPDF_KVJP: no cov read, no d/dcov write); every other shape composes the existing kernels on library-owned
+// scratch (spectrum -> fused value + gradient -> kernel reverse mode), same results.
+int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx* c, int matern, double nu, const double* y, int64_t y_bs, const double* loc,
+                                 int64_t loc_bs, const double* params, double nugget, int64_t H, int64_t W,
+                                 int64_t batch, int dim1, double* lpdf, double* grad_y, double* params_bar,
+                                 double* min_eig) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    if (!y || !params || !lpdf || !grad_y) return fail(c, GPT_ERR_SHAPE, "y, params, lpdf and grad_y must not be null");
+    if (matern && !(nu > 0)) return fail(c, GPT_ERR_SHAPE, "nu must be positive");
+    if (batch == 0) return GPT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool fused = !dim1 && path_for_shape(H, W) == 1 && gpt_pow2_sub_radix(OP_LPDF_KVJP, (int)H, (int)W) != 0;
+    if (fused) {
+        if ((rc = ensure(c, c->kscr, c->kscr_bytes, sizeof(double) * 4 * (size_t)batch)) != GPT_OK) return rc;
+        LatArgs a = base_args(H, W, batch, 0);
+        a.x = y; a.x_bs = y_bs;
+        a.loc = loc; a.loc_bs = loc_bs;
+        a.out = grad_y;
+        a.min_eig = min_eig;
+        a.kpar = params;
+        a.kmatern = matern ? 1 : 0;
+        a.knu = nu;
+        a.kgamma = matern ? gamma_ratio(nu, 0) : 0.0;
+        a.knugget = nugget;
+        a.ksums = c->kscr;
+        if ((rc = run_lattice(c, OP_LPDF_KVJP, a)) != GPT_OK) return rc;
+        HIP_TRY(c, gpt_launch_kvjp_combine(c->kscr, params, batch, lpdf, params_bar, c->stream));
+        return GPT_OK;
+    }
+    // composed: cov and d/dcov live in scratch, a chunk of lattices at a time (<= ~256 MiB)
+    const size_t hwf = (size_t)H * (size_t)(W / 2 + 1);
+    int64_t chunk = (int64_t)((size_t)(128u << 20) / (hwf * sizeof(double)));
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    if ((rc = ensure(c, c->kscr, c->kscr_bytes, 2 * sizeof(double) * hwf * (size_t)chunk)) != GPT_OK) return rc;
+    double* cov = c->kscr;
+    double* dcov = c->kscr + hwf * (size_t)chunk;
+    const int npar = dim1 ? 3 : 5;
+    for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
+        const int64_t nb = batch - b0 < chunk ? batch - b0 : chunk;
+        ElemArgs e = elem_args(H, W, nb, dim1);
+        e.par = params + b0 * npar;
+        e.out = cov;
+        e.nu = nu;
+        e.gamma_ratio = matern ? gamma_ratio(nu, dim1) : 0.0;
+        e.nugget = nugget;
+        if ((rc = run_elem(c, matern ? EL_MATERN : EL_EXPQUAD, e, false, 0, 0.0, nullptr, nullptr)) != GPT_OK) return rc;
+        if ((rc = gpt_gp_rfft2_lpdf_vjp(c, y + b0 * y_bs, y_bs, loc ? loc + b0 * loc_bs : nullptr, loc_bs, cov, (int64_t)hwf,
+                                        H, W, nb, dim1, lpdf + b0, grad_y + b0 * H * W, params_bar ? dcov : nullptr,
+                                        min_eig ? min_eig + b0 : nullptr)) != GPT_OK)
+            return rc;
+        if (params_bar) {
+            ElemArgs v = elem_args(H, W, nb, dim1);
+            v.par = params + b0 * npar;
+            v.in = dcov;
+            v.in_bs = (int64_t)hwf;
+            v.nu = nu;
+            v.gamma_ratio = e.gamma_ratio;
+            if ((rc = run_elem(c, matern ? EL_MATERN_VJP : EL_EXPQUAD_VJP, v, true, npar, 0.0, params_bar + b0 * npar,
+                               nullptr)) != GPT_OK)
+                return rc;
+        }
+    }
+    return GPT_OK;
 }
 
 int gpt_gp_periodic_exp_quad_cov_rfft2(gpt_ctx* c, int64_t H, int64_t W, const double* params, int64_t batch,

@@ -445,6 +445,34 @@ def _params(dim1, sigma, length_scale, period, device=None):
     return torch.stack(cols, dim=-1).contiguous(), tuple(bshape)
 
 
+def _lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget, dim1, check):
+    g = _prep(y, loc, None, dim1)
+    par, pshape = _params(dim1, sigma, length_scale, period, g["main"].device)
+    if pshape != g["bshape"]:
+        par = par.expand(*g["bshape"], par.shape[-1]).contiguous()
+    lp, mn = _new(g), _new(g)
+    gy = torch.empty_like(g["main"])
+    pbar = torch.empty_like(par)
+    get_context(lp.device).call("gpt_gp_rfft2_lpdf_kernel_vjp", int(kind != "expquad"), float(nu), _p(g["main"]),
+                                g["m_bs"], _p(g["loc"]), g["l_bs"], _p(par), float(nugget), g["H"], g["W"], g["B"],
+                                g["dim1"], _p(lp), _p(gy), _p(pbar), _p(mn))
+    _check_pd(mn, check)
+    if dim1:
+        return lp, gy, (pbar[..., 0], pbar[..., 1], pbar[..., 2])
+    return lp, gy, (pbar[..., 0], pbar[..., 1:3], pbar[..., 3:5])
+
+
+def gp_rfft2_lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget=0.0, check=True):
+    """``gp_rfft2_lpdf(y | loc, kernel + nugget)`` (fft2.stan:189-192 over :206-247) without materialising the spectrum:
+    ``(lpdf, d/dy, (d/dsigma, d/dlength_scale, d/dperiod))``. ``kind``: ``"expquad"`` or ``"matern"`` (``nu``)."""
+    return _lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget, False, check)
+
+
+def gp_rfft_lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget=0.0, check=True):
+    """1-D sibling (fft1.stan:96-101 over :154-176)."""
+    return _lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget, True, check)
+
+
 def _spec(kind, nu, height, width, sigma, length_scale, period, dim1):
     par, bshape = _params(dim1, sigma, length_scale, period)
     Wf = width // 2 + 1

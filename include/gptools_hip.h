@@ -188,6 +188,18 @@ int gpt_gp_periodic_matern_cov_rfft2_vjp(gpt_ctx*, double nu, int64_t height, in
                                          const double* params, const double* covbar, int64_t covbar_bs,
                                          int64_t batch, int dim1, double* params_bar);
 
+/* Kernel-fused log density (in the reference: gp_periodic_*_cov_rfft2 (fft2.stan:206-247) + the
+ * model's nugget (docs/padding/padded.stan:21) feeding gp_rfft2_lpdf (fft2.stan:189-192), three functions and two
+ * H x (W/2+1) temporaries): lpdf[b] = gp_rfft2_lpdf(y[b] | loc, kernel(params[b]) + nugget) with the reverse mode
+ * grad_y[batch][H][W] and params_bar[batch][5] (or [3] for dim1; may be NULL) = d lpdf / d (sigma, length_scale,
+ * period); nu and the nugget are data. `matern` 0: periodic squared exponential, else Matern with smoothness nu.
+ * Power-of-two lattices of 512..8192 rows evaluate the spectrum inside the column pass and never store it; other
+ * shapes compose the existing kernels on library-owned scratch with identical results. */
+int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx*, int matern, double nu, const double* y, int64_t y_bs, const double* loc,
+                                 int64_t loc_bs, const double* params, double nugget, int64_t height, int64_t width,
+                                 int64_t batch, int dim1, double* lpdf, double* grad_y, double* params_bar,
+                                 double* min_eig);
+
 /* ---- host-pointer entry points (what the Stan user header binds) ----------------
  * One lattice per call (batch == 1), `layout` as above. Matrices are height x width (cov: height x
  * (width/2+1)). */

@@ -387,3 +387,47 @@ def test_subline_path_variants(fft):
     bad[1, 5, 77] = -2.0
     with pytest.raises(ValueError, match="not positive-definite"):
         fft.gp_rfft2_lpdf_vjp(y, loc, bad)
+
+
+@pytest.mark.parametrize("shape", [(1024, 1024), (512, 2048), (35, 60), (128,)], ids=str)
+@pytest.mark.parametrize("kind,nu", [("matern", 1.5), ("matern", 2.5), ("matern", 0.9), ("expquad", 0.0)])
+def test_kernel_fused_lpdf(fft, shape, kind, nu):
+    """gp_rfft2_lpdf over gp_periodic_*_cov_rfft2 + nugget without the spectrum in memory (power-of-two lattices of
+    >= 512 rows: evaluated inside the column pass; other shapes: composed), against the oracle's composition of the
+    three reference functions and the chain rule."""
+    dim1 = len(shape) == 1
+    rng = np.random.default_rng(11)
+    b = 2
+    y = rng.normal(size=(b,) + shape)
+    loc = rng.normal(size=shape)
+    sigma = np.array([1.3, 0.7])
+    eps = 1e-3
+    if dim1:
+        n = shape[0]
+        ls, per = np.array([n / 12.0, n / 20.0]), np.array([float(n), 1.5 * n])
+        lp, gy, (sb, lb, pb) = fft.gp_rfft_lpdf_kernel_vjp(y, loc, kind, nu, sigma, ls, per, nugget=eps)
+    else:
+        h, w = shape
+        ls = np.array([[h / 40.0, w / 30.0], [h / 25.0, w / 50.0]])
+        per = np.array([[float(h), float(w)], [1.2 * h, 0.9 * w]])
+        lp, gy, (sb, lb, pb) = fft.gp_rfft2_lpdf_kernel_vjp(y, loc, kind, nu, sigma, ls, per, nugget=eps)
+    for i in range(b):
+        if dim1:
+            cov = (o.gp_periodic_exp_quad_cov_rfft(n, sigma[i], ls[i], per[i]) if kind == "expquad"
+                   else o.gp_periodic_matern_cov_rfft(nu, n, sigma[i], ls[i], per[i])) + eps
+            lp_o, gy_o, gc_o = o.gp_rfft_lpdf_vjp(y[i], loc, cov)
+            bars = (o.gp_periodic_exp_quad_cov_rfft_vjp(n, sigma[i], ls[i], per[i], gc_o) if kind == "expquad"
+                    else o.gp_periodic_matern_cov_rfft_vjp(nu, n, sigma[i], ls[i], per[i], gc_o))
+        else:
+            cov = (o.gp_periodic_exp_quad_cov_rfft2(h, w, sigma[i], ls[i], per[i]) if kind == "expquad"
+                   else o.gp_periodic_matern_cov_rfft2(nu, h, w, sigma[i], ls[i], per[i])) + eps
+            lp_o, gy_o, gc_o = o.gp_rfft2_lpdf_vjp(y[i], loc, cov)
+            bars = (o.gp_periodic_exp_quad_cov_rfft2_vjp(h, w, sigma[i], ls[i], per[i], gc_o) if kind == "expquad"
+                    else o.gp_periodic_matern_cov_rfft2_vjp(nu, h, w, sigma[i], ls[i], per[i], gc_o))
+        close(lp[i], lp_o)
+        close(gy[i], gy_o)
+        # the parameter gradients are sums of ~n terms of both signs: tolerance relative to the sum of magnitudes
+        scale = float(np.abs(gc_o * cov).sum())
+        for got, want, p in zip((sb[i], lb[i], pb[i]), bars, (sigma[i], ls[i], per[i])):
+            np.testing.assert_allclose(np.asarray(got.cpu()), want, rtol=1e-9,
+                                       atol=1e-10 * scale / float(np.min(np.abs(p))))
