@@ -186,6 +186,8 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
         if (s.out_c) s.out_c += b0 * hwf;
         if (s.out_lpdf) s.out_lpdf += b0;
         if (s.min_eig) s.min_eig += b0;
+        if (s.kpar) s.kpar += b0 * 5;
+        if (s.ksums) s.ksums += b0 * 4;
         if (path != 1) {
             HIP_TRY(c, gpt_launch_generic(op, s, c->ws, c->partials, c->stream));
             continue;
@@ -675,7 +677,10 @@ int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx* c, int matern, double nu, const double
     if (matern && !(nu > 0)) return fail(c, GPT_ERR_SHAPE, "nu must be positive");
     if (batch == 0) return GPT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    const bool fused = !dim1 && path_for_shape(H, W) == 1 && gpt_pow2_sub_radix(OP_LPDF_KVJP, (int)H, (int)W) != 0;
+    // the fused evaluation knows exp-quad and half-integer Matern smoothness (nu = 0.5, 1.5, ... 5.5)
+    const bool nu_ok = !matern || (nu <= 5.5 && nu - std::floor(nu) == 0.5 /* kern_eval */);
+    const bool fused = !dim1 && nu_ok && path_for_shape(H, W) == 1 &&
+                       gpt_pow2_sub_radix(OP_LPDF_KVJP, (int)H, (int)W) != 0;
     if (fused) {
         if ((rc = ensure(c, c->kscr, c->kscr_bytes, sizeof(double) * 4 * (size_t)batch)) != GPT_OK) return rc;
         LatArgs a = base_args(H, W, batch, 0);
@@ -689,7 +694,7 @@ int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx* c, int matern, double nu, const double
         a.kgamma = matern ? gamma_ratio(nu, 0) : 0.0;
         a.knugget = nugget;
         a.ksums = c->kscr;
-        if ((rc = run_lattice(c, OP_LPDF_KVJP, a)) != GPT_OK) return rc;
+        if ((rc = run_lattice(c, matern ? OP_LPDF_KVJP : OP_LPDF_KVJP_EQ, a)) != GPT_OK) return rc;
         HIP_TRY(c, gpt_launch_kvjp_combine(c->kscr, params, batch, lpdf, params_bar, c->stream));
         return GPT_OK;
     }

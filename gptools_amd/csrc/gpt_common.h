@@ -31,20 +31,22 @@ enum GptOp : int {
     OP_LPDF_VJP_NOCOV = 8, // OP_LPDF_VJP without d/dcov (caller passed grad_cov == NULL)
     OP_LPDF_KVJP = 9,    // OP_LPDF_VJP with the spectrum evaluated on the fly from kernel parameters
                          // (fft2.stan:206-247 + nugget) and d/dcov contracted into d/d(sigma, length_scale, period)
-    OP_COUNT = 10
+    OP_LPDF_KVJP_EQ = 10, // ... periodic squared exponential kernel (OP_LPDF_KVJP: Matern)
+    OP_COUNT = 11
 };
+__host__ __device__ constexpr bool op_is_kvjp(int op) { return op == OP_LPDF_KVJP || op == OP_LPDF_KVJP_EQ; }
 
 __host__ __device__ constexpr bool op_is_lpdf_vjp(int op) {
-    return op == OP_LPDF_VJP || op == OP_LPDF_VJP_NOCOV || op == OP_LPDF_KVJP;
+    return op == OP_LPDF_VJP || op == OP_LPDF_VJP_NOCOV || op == OP_LPDF_KVJP || op == OP_LPDF_KVJP_EQ;
 }
 
 __host__ __device__ constexpr bool op_has_fwd(int op) {
     return op == OP_RFFT2 || op == OP_GP_RFFT2 || op == OP_LPDF || op == OP_LPDF_VJP ||
-           op == OP_INV_VJP || op == OP_FWD_VJP || op == OP_LPDF_VJP_NOCOV || op == OP_LPDF_KVJP;
+           op == OP_INV_VJP || op == OP_FWD_VJP || op == OP_LPDF_VJP_NOCOV || op_is_kvjp(op);
 }
 __host__ __device__ constexpr bool op_has_inv(int op) {
     return op == OP_INV_RFFT2 || op == OP_GP_INV_RFFT2 || op == OP_LPDF_VJP || op == OP_FWD_VJP ||
-           op == OP_LPDF_VJP_NOCOV || op == OP_LPDF_KVJP;
+           op == OP_LPDF_VJP_NOCOV || op_is_kvjp(op);
 }
 
 // One line-FFT plan (any length): Stockham stages with radices r[0..ns).
@@ -282,30 +284,34 @@ __device__ __forceinline__ EwPtrs make_ptrs(const LatArgs& a, int64_t b) {
 struct KernVal {
     double ck, f1, f2;
 };
+template <bool MATERN>
 __device__ __forceinline__ KernVal kern_eval(const LatArgs& a, const double* par, int i, int j) {
     constexpr double PI_ = 3.14159265358979323846;
     const double sigma = par[0], l1 = par[1], l2 = par[2], p1 = par[3], p2 = par[4];
     const int ki = (i <= a.H / 2) ? i : a.H - i;
-    const double a1 = (double)ki * l1 / p1, a2 = (double)j * l2 / p2;
+    const double r1 = l1 / p1, r2 = l2 / p2; // uniform
+    const double a1 = (double)ki * r1, a2 = (double)j * r2;
     const double s1 = a1 * a1, s2 = a2 * a2;
-    const double amp = sigma * sigma * (double)a.H * (double)a.W * (l1 / p1) * (l2 / p2);
+    const double amp = sigma * sigma * (double)a.H * (double)a.W * r1 * r2;
     KernVal v;
-    if (!a.kmatern) {
+    if (!MATERN) {
         v.ck = amp * (2.0 * PI_) * exp(-2.0 * PI_ * PI_ * (s1 + s2));
         v.f1 = 4.0 * PI_ * PI_ * s1;
         v.f2 = 4.0 * PI_ * PI_ * s2;
         return v;
     }
-    const double arg = 1.0 + 2.0 / a.knu * PI_ * PI_ * (s1 + s2);
+    const double tn = 2.0 / a.knu * PI_ * PI_; // uniform
+    const double arg = fma(tn, s1 + s2, 1.0);
     const double inv = 1.0 / arg;
-    // arg^-(nu + 1): half-integer smoothness (the reference's Python mirror allows nothing else, kernels.py:306)
-    // needs a square root and a few products; anything else the general power
-    double pw;
-    const double twonu = 2.0 * a.knu;
-    if (twonu == 3.0) pw = inv * inv * sqrt(inv);
-    else if (twonu == 5.0) pw = inv * inv * inv * sqrt(inv);
-    else if (twonu == 1.0) pw = inv * sqrt(inv);
-    else pw = pow(arg, -(a.knu + 1.0));
+    // arg^-(nu + 1) for half-integer smoothness nu = m - 1/2, m = 1..6 (the reference's Python mirror allows 1.5 and
+    // 2.5 only, kernels.py:306): a square root and a few products; selects with
+    // trivial arms only (a nested choice of products became 32 branchy copies and 400 spilled registers). Other values never get
+    // here (gpt_api.hip composes them).
+    const int m = (int)(a.knu + 0.5);
+    const double i2 = inv * inv, i4 = i2 * i2;
+    const double t1 = (m & 1) ? inv : 1.0, t2 = (m & 2) ? i2 : 1.0, t4 = (m & 4) ? i4 : 1.0; // plain selects
+    const double im = t1 * t2 * t4;
+    const double pw = sqrt(inv) * im;
     v.ck = amp * 4.0 * (PI_ / (2.0 * a.knu)) * a.kgamma * pw;
     const double g = (a.knu + 1.0) * (4.0 * PI_ * PI_ / a.knu) * inv;
     v.f1 = g * s1;
@@ -339,8 +345,8 @@ __device__ __forceinline__ cplx ew_interior_c(const LatArgs& a, const ZLayout& L
         return P.cin[ic];
     }
     KernVal kv = {0.0, 0.0, 0.0};
-    if (OP == OP_LPDF_KVJP) { // `c` is not an input: the kernel is evaluated here
-        kv = kern_eval(a, P.kpar, i, j);
+    if (op_is_kvjp(OP)) { // `c` is not an input: the kernel is evaluated here
+        kv = kern_eval<OP == OP_LPDF_KVJP>(a, P.kpar, i, j);
         c = kv.ck + a.knugget;
     }
     acc.mn = fmin(acc.mn, 0.5 * n * c);
@@ -360,7 +366,7 @@ __device__ __forceinline__ cplx ew_interior_c(const LatArgs& a, const ZLayout& L
         acc_log(acc, c);
         if (op_is_lpdf_vjp(OP)) {
             if (OP == OP_LPDF_VJP) P.out_cov[ic] = (q - 1.0) * inv_c;
-            if (OP == OP_LPDF_KVJP) acc_kern(acc, kv, (q - 1.0) * inv_c);
+            if (op_is_kvjp(OP)) acc_kern(acc, kv, (q - 1.0) * inv_c);
             ret = cscale(F, inv_c);
         }
     } else if (OP == OP_INV_VJP) {
@@ -387,7 +393,7 @@ template <int OP>
 __device__ __forceinline__ cplx ew_interior(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int i, int j,
                                            cplx F, EwAcc& acc) {
     double c = 1.0;
-    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && OP != OP_LPDF_KVJP) c = P.cov[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && !op_is_kvjp(OP)) c = P.cov[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
     return ew_interior_c<OP>(a, L, P, i, j, F, c, acc);
 }
 
@@ -423,8 +429,8 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
         return make_double2(0.5 * (u.x + v.x), 0.5 * (u.y - v.y));
     }
     KernVal kv = {0.0, 0.0, 0.0};
-    if (OP == OP_LPDF_KVJP) { // rows are mirrored in the kernel: the mirror row has the same value
-        kv = kern_eval(a, P.kpar, k, j);
+    if (op_is_kvjp(OP)) { // rows are mirrored in the kernel: the mirror row has the same value
+        kv = kern_eval<OP == OP_LPDF_KVJP>(a, P.kpar, k, j);
         c = cm = kv.ck + a.knugget;
     }
     if (real_pt) cm = c;
@@ -459,7 +465,7 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
                     if (P.edge_dcov) P.edge_dcov[(j ? a.H : 0) + k] = 0.5 * (q - 1.0) * inv_c;
                     else P.out_cov[ck] = 0.5 * (q - 1.0) * inv_c;
                 }
-                if (OP == OP_LPDF_KVJP) acc_kern(acc, kv, 0.5 * (q - 1.0) * inv_c);
+                if (op_is_kvjp(OP)) acc_kern(acc, kv, 0.5 * (q - 1.0) * inv_c);
                 ret = make_double2(FA.x * inv_c, 0.0);
             }
         } else {
@@ -475,7 +481,7 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
                         P.out_cov[cm_] = 0.0;
                     }
                 }
-                if (OP == OP_LPDF_KVJP) acc_kern(acc, kv, (q - 1.0) * inv_c);
+                if (op_is_kvjp(OP)) acc_kern(acc, kv, (q - 1.0) * inv_c);
                 ret = cscale(FA, inv_c);
             }
         }
@@ -517,7 +523,7 @@ template <int OP>
 __device__ __forceinline__ cplx ew_edge(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k, int j, cplx FA,
                                        EwAcc& acc) {
     double c = 1.0, cm = 1.0;
-    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && OP != OP_LPDF_KVJP) {
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && !op_is_kvjp(OP)) {
         const bool real_pt = (k == 0) || (2 * k == a.H);
         c = P.cov[(unsigned)k * (unsigned)L.Wf + (unsigned)j];
         cm = real_pt ? c : P.cov[(unsigned)(a.H - k) * (unsigned)L.Wf + (unsigned)j];
@@ -532,7 +538,7 @@ struct EdgeCov {
 template <int OP>
 __device__ __forceinline__ EdgeCov load_edge_cov(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int k) {
     EdgeCov e = {1.0, 1.0, 1.0, 1.0};
-    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && OP != OP_LPDF_KVJP) {
+    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && !op_is_kvjp(OP)) {
         const bool real_pt = (k == 0) || (2 * k == a.H);
         if (P.edge_cov) {
             const int km = real_pt ? k : a.H - k;

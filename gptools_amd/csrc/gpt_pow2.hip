@@ -95,7 +95,7 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
     const double n = (double)a.H * (double)a.W;
     const int R = (a.ncols == 0 && a.tw_sub) ? gpt_pow2_sub_radix(op, a.H, a.W) : 0;
     const bool sub = R != 0;
-    if (op == OP_LPDF_KVJP && !sub) return hipErrorInvalidValue; // only the sub-line kernel evaluates the spectrum
+    if (op_is_kvjp(op) && !sub) return hipErrorInvalidValue; // only the sub-line kernel evaluates the spectrum
     const int nblk = sub ? sub_col_blocks(R, a.H, a.W, col_cus) : whole_col_blocks(a.H, a.W, col_cus);
     const bool reduces = (op != OP_RFFT2 && op != OP_INV_RFFT2);
     const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op));
@@ -122,7 +122,7 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
             e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, ws, wstride, partials, nblk, edge_flags ? edge : nullptr, edge_flags, st); });
         if (e != hipSuccess) return e;
         // second reduction stage: folded into pass C when there is one
-        if (op == OP_LPDF_KVJP) // four sums per lattice: their own reduction launch
+        if (op_is_kvjp(op)) // four sums per lattice: their own reduction launch
             return gpt_launch_finalize(partials, nblk, a.batch, 4, add, a.ksums, a.min_eig, st);
         if (reduces && !op_has_inv(op))
             e = gpt_launch_finalize(partials, nblk, a.batch, 1, add, lp ? a.out_lpdf : nullptr, a.min_eig, st);
@@ -131,7 +131,7 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
     if (pass == 2) {
         if (!op_has_inv(op)) return hipSuccess;
         FinArgs fin = {nullptr, 0, 0.0, nullptr, nullptr};
-        if (reduces && op != OP_LPDF_KVJP) {
+        if (reduces && !op_is_kvjp(op)) {
             fin.partials = partials;
             fin.nblk = nblk;
             fin.add = add;

@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
     using G = GeoS<HS, V, THREADS>;
     constexpr int T = G::T, TC = G::TC, TP = G::TP;
     constexpr int NPRE = tw_npre<HS>();
-    constexpr bool NEEDS_COV = (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && OP != OP_LPDF_KVJP); // cov is LOADED
+    constexpr bool NEEDS_COV = (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && !op_is_kvjp(OP)); // cov is LOADED
     // timing-only experiments (GPT_EXP bits; results wrong): 1 = no d/dcov stores, 2 = no cov loads, 4 = cov and
     // d/dcov rows addressed with an aligned stride (Wf - 1), 8 = cov read from 64 rows only (cache hits)
     constexpr int EWOP = (GPT_EXP & 1) && OP == OP_LPDF_VJP ? (int)OP_LPDF_VJP_NOCOV : OP;
@@ -314,9 +314,12 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
                                     : 1.0;
 #pragma unroll
                     for (int m = 0; m < CVN; ++m) {
-                        v[k][m0 + m] =
-                            ew_interior_c<EWOP>(a, LE, P, R * (tl[k] + T * (m0 + m)) + q, jp, v[k][m0 + m], cv[m], acc);
-                        if ((m & 3) == 3) SCHED_FENCE();
+                        int irow = R * (tl[k] + T * (m0 + m)) + q;
+                        // (kernel-fused op: pin the row index here, or the 32 kernel evaluations of a thread are
+                        // started side by side and spill)
+                        if (op_is_kvjp(OP)) asm volatile("" : "+v"(irow));
+                        v[k][m0 + m] = ew_interior_c<EWOP>(a, LE, P, irow, jp, v[k][m0 + m], cv[m], acc);
+                        if ((m & 3) == 3 || op_is_kvjp(OP)) SCHED_FENCE(); // (the kernel evaluation is long)
                     }
                     SCHED_FENCE();
                 }
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
     if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
         double s = acc.sum, mn = acc.mn;
         double kk[3] = {acc.k0, acc.k1, acc.k2};
-        if (OP == OP_LPDF_KVJP) {
+        if (op_is_kvjp(OP)) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) { // (block_sum_min below ends with a barrier-protected read by thread 0)
                 double t = kk[i], dummy = 0.0;
@@ -367,9 +370,9 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
         if (threadIdx.x == 0) {
             double* p = partials + ((int64_t)b * gridDim.x + blockIdx.x) * GPT_PART;
             p[0] = s;
-            p[1] = OP == OP_LPDF_KVJP ? kk[0] : 0.0;
-            p[2] = OP == OP_LPDF_KVJP ? kk[1] : 0.0;
-            p[3] = OP == OP_LPDF_KVJP ? kk[2] : 0.0;
+            p[1] = op_is_kvjp(OP) ? kk[0] : 0.0;
+            p[2] = op_is_kvjp(OP) ? kk[1] : 0.0;
+            p[3] = op_is_kvjp(OP) ? kk[2] : 0.0;
             p[4] = 0.0;
             p[5] = mn;
         }

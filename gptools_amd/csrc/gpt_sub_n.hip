@@ -108,6 +108,8 @@ hipError_t LaunchSub<GPT_N>::colsub(int op, const LatArgs& a, int R, cplx* ws, i
     case OP_LPDF_VJP_NOCOV:
         return colsub_t<OP_LPDF_VJP_NOCOV>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
     case OP_LPDF_KVJP: return colsub_t<OP_LPDF_KVJP>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    case OP_LPDF_KVJP_EQ:
+        return colsub_t<OP_LPDF_KVJP_EQ>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
     default: return hipErrorInvalidValue;
     }
 }
