@@ -287,6 +287,19 @@ def main():
             dom = max(kernels, key=lambda k: k["avg_ms_per_eval"])
             result["roofline"]["dominant_kernel"] = {"name": dom["name"], "GBps": dom["GBps"],
                                                      "frac": dom["GBps"] * 1e9 / HBM_PEAK}
+        if world == 1:
+            # what this box's HBM delivers to a plain streaming copy (read + write bytes), beside the nominal peak
+            src = torch.empty(1 << 27, dtype=torch.float64, device=device)  # 1 GiB
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            c1.record()
+            torch.cuda.synchronize()
+            result["roofline"]["measured_copy_GBps"] = 10 * 2 * src.numel() * 8 / (1e-3 * c0.elapsed_time(c1)) / 1e9
+            del src, dst
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(size)
         print(json.dumps(result))

@@ -22,6 +22,9 @@
 
 namespace pow2 {
 
+#ifndef GPT_TW_RELOAD
+#define GPT_TW_RELOAD 0
+#endif
 #ifndef GPT_CVN
 #define GPT_CVN 0
 #endif
@@ -339,8 +342,13 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
             for (int k = 0; k < V; ++k) {
                 t_inv[k] = tl[k];
                 asm volatile("" : "+v"(t_inv[k]), "+v"(v[0][0].x));
+#if GPT_TW_RELOAD
+                // the twiddle bases are fetched again (cached table) instead of living through the elementwise stage
+                tw_load<HS>(wl[k], tws, t_inv[k]);
+#else
 #pragma unroll
                 for (int i = 0; i < NPRE; ++i) asm volatile("" : "+v"(wl[k][i].x), "+v"(wl[k][i].y), "+v"(v[0][0].x));
+#endif
             }
             fft_regs<HS, true, V, 0>(v, t_inv, lds, wl);
             TRACE_MARK(r, 6); // inverse transform done
