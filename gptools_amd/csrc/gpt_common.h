@@ -330,11 +330,11 @@ __device__ __forceinline__ void acc_kern(EwAcc& acc, const KernVal& kv, double c
 // Elementwise stage, INTERIOR entry (i, j), 1 <= j <= wc: a "complex pair" whose Re and Im are both
 // whitened with s^2 = n c / 2 (fft2.stan:13-40, 67-68). F is the spectrum value on entry (ops with a
 // forward transform); the return value replaces it (ops with an inverse transform).
+// `ic` = i * Wf + j, the offset into H x Wf arrays (callers that walk rows at a fixed stride have it for an addition)
 template <int OP>
-__device__ __forceinline__ cplx ew_interior_c(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int i, int j,
-                                             cplx F, double c, EwAcc& acc) {
+__device__ __forceinline__ cplx ew_interior_ic(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int i, int j,
+                                              unsigned ic, cplx F, double c, EwAcc& acc) {
     const double n = (double)a.H * (double)a.W;
-    const unsigned ic = (unsigned)i * (unsigned)L.Wf + (unsigned)j; // offset into H x Wf arrays
     const unsigned iz = (unsigned)i * (unsigned)a.W;                // row offset into H x W arrays
     cplx ret = F;
     if (OP == OP_RFFT2) {
@@ -386,6 +386,12 @@ __device__ __forceinline__ cplx ew_interior_c(const LatArgs& a, const ZLayout& L
         ret = make_double2(0.5 * qr / s, 0.5 * qi / s);
     }
     return ret;
+}
+
+template <int OP>
+__device__ __forceinline__ cplx ew_interior_c(const LatArgs& a, const ZLayout& L, const EwPtrs& P, int i, int j,
+                                             cplx F, double c, EwAcc& acc) {
+    return ew_interior_ic<OP>(a, L, P, i, j, (unsigned)i * (unsigned)L.Wf + (unsigned)j, F, c, acc);
 }
 
 // Same, loading c itself (ops without cov never touch the pointer).

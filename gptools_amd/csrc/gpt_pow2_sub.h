@@ -245,10 +245,10 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
 #pragma unroll
         for (int k = 0; k < V; ++k)
 #pragma unroll
-            for (int m = 0; m < E; ++m)
-                v[k][m] = (op_has_fwd(OP) && !skip)
-                              ? wsb[(unsigned)(rowq + tl[k] + T * m) * (unsigned)wstride + (unsigned)jl]
-                              : make_double2(0.0, 0.0);
+            for (int m = 0; m < E; ++m) // (the lanes of the packed column 0 load it too: no per-load predicate)
+                v[k][m] = op_has_fwd(OP) ? wsb[(unsigned)(rowq + tl[k]) * (unsigned)wstride + (unsigned)jl +
+                                               (unsigned)(T * m) * (unsigned)wstride]
+                                         : make_double2(0.0, 0.0);
 #if GPT_TRACE
         TRACE_MARK(r, 1); // loads issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -307,21 +307,27 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
             } else {
 #pragma unroll
             for (int k = 0; k < V; ++k) {
+                // offsets into cov / d/dcov: one multiplication per register tile, the rows of a tile are a uniform
+                // stride apart
+                const unsigned icb = (unsigned)(R * tl[k] + q) * (unsigned)LE.Wf + (unsigned)jp;
+                const unsigned icstep = (unsigned)(R * T) * (unsigned)LE.Wf;
 #pragma unroll
                 for (int m0 = 0; m0 < E; m0 += CVN) {
                     double cv[CVN];
 #pragma unroll
-                    for (int m = 0; m < CVN; ++m)
-                        cv[m] = (NEEDS_COV && !(GPT_EXP & 2))
-                                    ? P.cov[(unsigned)((R * (tl[k] + T * (m0 + m)) + q) & ((GPT_EXP & 8) ? 63 : 0x7fffffff)) * (unsigned)LE.Wf + (unsigned)jp]
-                                    : 1.0;
+                    for (int m = 0; m < CVN; ++m) {
+                        unsigned ic = icb + (unsigned)(m0 + m) * icstep;
+                        if (GPT_EXP & 8) ic = (unsigned)((R * (tl[k] + T * (m0 + m)) + q) & 63) * (unsigned)LE.Wf + (unsigned)jp;
+                        cv[m] = (NEEDS_COV && !(GPT_EXP & 2)) ? P.cov[ic] : 1.0;
+                    }
 #pragma unroll
                     for (int m = 0; m < CVN; ++m) {
                         int irow = R * (tl[k] + T * (m0 + m)) + q;
                         // (kernel-fused op: pin the row index here, or the 32 kernel evaluations of a thread are
                         // started side by side and spill)
                         if (op_is_kvjp(OP)) asm volatile("" : "+v"(irow));
-                        v[k][m0 + m] = ew_interior_c<EWOP>(a, LE, P, irow, jp, v[k][m0 + m], cv[m], acc);
+                        v[k][m0 + m] = ew_interior_ic<EWOP>(a, LE, P, irow, jp, icb + (unsigned)(m0 + m) * icstep,
+                                                            v[k][m0 + m], cv[m], acc);
                         if ((m & 3) == 3 || op_is_kvjp(OP)) SCHED_FENCE(); // (the kernel evaluation is long)
                     }
                     SCHED_FENCE();
@@ -357,7 +363,8 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
                 for (int k = 0; k < V; ++k)
 #pragma unroll
                     for (int m = 0; m < E; ++m)
-                        wsb[(unsigned)(rowq + t_inv[k] + T * m) * (unsigned)wstride + (unsigned)jl] = v[k][m];
+                        wsb[(unsigned)(rowq + t_inv[k]) * (unsigned)wstride + (unsigned)jl +
+                            (unsigned)(T * m) * (unsigned)wstride] = v[k][m];
             }
             TRACE_MARK(r, 7);
         }
