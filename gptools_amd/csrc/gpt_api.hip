@@ -679,8 +679,9 @@ int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx* c, int matern, double nu, const double
     HIP_TRY(c, hipSetDevice(c->device));
     // the fused evaluation knows exp-quad and half-integer Matern smoothness (nu = 0.5, 1.5, ... 5.5)
     const bool nu_ok = !matern || (nu <= 5.5 && nu - std::floor(nu) == 0.5 /* kern_eval */);
-    const bool fused = !dim1 && nu_ok && path_for_shape(H, W) == 1 &&
-                       gpt_pow2_sub_radix(OP_LPDF_KVJP, (int)H, (int)W) != 0;
+    const int path = path_for_shape(H, W);
+    const bool fused = !dim1 && nu_ok &&
+                       (path == 0 || (path == 1 && gpt_pow2_sub_radix(OP_LPDF_KVJP, (int)H, (int)W) != 0));
     if (fused) {
         if ((rc = ensure(c, c->kscr, c->kscr_bytes, sizeof(double) * 4 * (size_t)batch)) != GPT_OK) return rc;
         LatArgs a = base_args(H, W, batch, 0);

@@ -102,10 +102,25 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
     }
     if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
         double s = acc.sum, m = acc.mn;
+        double kk[3] = {acc.k0, acc.k1, acc.k2};
+        if (op_is_kvjp(OP)) { // kernel-fused op: the three sums behind d/d(sigma, length_scale, period)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double t = kk[i], dummy = 0.0;
+                block_sum_min(t, dummy, red);
+                kk[i] = t;
+            }
+        }
         block_sum_min(s, m, red);
         if (threadIdx.x == 0) {
-            if ((OP == OP_LPDF || op_is_lpdf_vjp(OP)) && a.out_lpdf)
-                a.out_lpdf[b] = s - 0.5 * (double)H * (double)W * 1.8378770664093454836;
+            const double lp = s - 0.5 * (double)H * (double)W * 1.8378770664093454836;
+            if ((OP == OP_LPDF || op_is_lpdf_vjp(OP)) && a.out_lpdf) a.out_lpdf[b] = lp;
+            if (op_is_kvjp(OP) && a.ksums) {
+                a.ksums[4 * b] = lp;
+                a.ksums[4 * b + 1] = kk[0];
+                a.ksums[4 * b + 2] = kk[1];
+                a.ksums[4 * b + 3] = kk[2];
+            }
             if (a.min_eig) a.min_eig[b] = m;
         }
     }
@@ -197,6 +212,8 @@ hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st) {
     case OP_INV_VJP: return launch_small_t<OP_INV_VJP>(a, cap, sS, nthreads, lds, st);
     case OP_FWD_VJP: return launch_small_t<OP_FWD_VJP>(a, cap, sS, nthreads, lds, st);
     case OP_LPDF_VJP_NOCOV: return launch_small_t<OP_LPDF_VJP_NOCOV>(a, cap, sS, nthreads, lds, st);
+    case OP_LPDF_KVJP: return launch_small_t<OP_LPDF_KVJP>(a, cap, sS, nthreads, lds, st);
+    case OP_LPDF_KVJP_EQ: return launch_small_t<OP_LPDF_KVJP_EQ>(a, cap, sS, nthreads, lds, st);
     default: return hipErrorInvalidValue;
     }
 }

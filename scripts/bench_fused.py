@@ -31,16 +31,17 @@ def timed(fn, iters):
 
 
 def main():
-    size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    h = w = size
+    # usage: bench_fused.py [height [width [batch]]]
+    h = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    w = int(sys.argv[2]) if len(sys.argv) > 2 else h
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     loc = torch.randn(h, w, dtype=torch.float64, device=dev, generator=g)
     y = loc + torch.randn(B, h, w, dtype=torch.float64, device=dev, generator=g)
     sigma = torch.linspace(1.0, 1.5, B, dtype=torch.float64, device=dev)
-    ls = torch.stack([torch.linspace(6.0, 10.0, B), torch.linspace(9.0, 14.0, B)], dim=-1).to(dev, torch.float64)
+    ls = torch.stack([torch.linspace(h / 12.0, h / 8.0, B), torch.linspace(w / 10.0, w / 7.0, B)], dim=-1).to(dev, torch.float64)
     per = torch.tensor([float(h), float(w)], dtype=torch.float64, device=dev).expand(B, 2)
     nu, eps = 1.5, 1e-3
 
@@ -55,7 +56,7 @@ def main():
     a, b = composed(), fused()
     rel = float(((a[0] - b[0]).abs() / a[0].abs()).max())
     relg = float((a[1] - b[1]).abs().max() / a[1].abs().max())
-    tc, tf = timed(composed, 5), timed(fused, 5)
+    tc, tf = timed(composed, 20), timed(fused, 20)
     n = h * w
     print(json.dumps({"case": f"{h}x{w}, batch {B}, Matern nu={nu}, per-lattice parameters",
                       "composed_us_per_eval": 1e6 * tc / B, "fused_us_per_eval": 1e6 * tf / B,
