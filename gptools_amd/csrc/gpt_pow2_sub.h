@@ -22,6 +22,9 @@
 
 namespace pow2 {
 
+#ifndef GPT_LOAD_PRED
+#define GPT_LOAD_PRED 0
+#endif
 #ifndef GPT_TW_RELOAD
 #define GPT_TW_RELOAD 0
 #endif
@@ -35,7 +38,7 @@ namespace pow2 {
 #define GPT_SUB_WPS1 4
 #endif
 #ifndef GPT_PRIO
-#define GPT_PRIO 1
+#define GPT_PRIO 0
 #endif
 #ifndef GPT_TOUCH
 #define GPT_TOUCH 0
@@ -246,9 +249,10 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
         for (int k = 0; k < V; ++k)
 #pragma unroll
             for (int m = 0; m < E; ++m) // (the lanes of the packed column 0 load it too: no per-load predicate)
-                v[k][m] = op_has_fwd(OP) ? wsb[(unsigned)(rowq + tl[k]) * (unsigned)wstride + (unsigned)jl +
-                                               (unsigned)(T * m) * (unsigned)wstride]
-                                         : make_double2(0.0, 0.0);
+                v[k][m] = (op_has_fwd(OP) && !(GPT_LOAD_PRED && skip))
+                              ? wsb[(unsigned)(rowq + tl[k]) * (unsigned)wstride + (unsigned)jl +
+                                    (unsigned)(T * m) * (unsigned)wstride]
+                              : make_double2(0.0, 0.0);
 #if GPT_TRACE
         TRACE_MARK(r, 1); // loads issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
