@@ -100,15 +100,15 @@ __global__ void __launch_bounds__(256) longrow_split(const cplx* __restrict__ tm
     }
 }
 
-// packed half spectrum rows 2 pair, 2 pair + 1 -> tmp[pair][q][k] = Z[8 k + q] (the full Hermitian-completed line)
+// packed half spectrum rows 2 pair, 2 pair + 1 -> tmp[pair][j % 8][j / 8] = Z[j] (the full Hermitian-completed line).
+// One thread = one frequency j: a wave reads 64 consecutive frequencies (the mirrored half descending) and writes eight
+// 128-byte pieces, one per sub-line -- the access pattern of longrow_split, mirrored.
 __global__ void __launch_bounds__(256) longrow_merge(const cplx* __restrict__ spec, int64_t ld, int W,
                                                      cplx* __restrict__ tmp) {
     const int WS = W / RW;
-    const int idx = blockIdx.x * 256 + threadIdx.x; // q * WS + k
+    const int j = blockIdx.x * 256 + threadIdx.x;
     const int64_t pair = blockIdx.y;
-    if (idx >= W) return;
-    const int q = idx / WS, k = idx - q * WS;
-    const int j = RW * k + q;
+    if (j >= W) return;
     const cplx* s0 = spec + 2 * pair * ld;
     const cplx* s1 = s0 + ld;
     cplx v;
@@ -117,15 +117,10 @@ __global__ void __launch_bounds__(256) longrow_merge(const cplx* __restrict__ sp
         v = j == 0 ? make_double2(A.x, B.x) : make_double2(A.x - B.y, A.y + B.x);
     } else {
         const int m = W - j; // 1 .. W/2
-        if (m == W / 2) {
-            const cplx A = s0[0], B = s1[0];
-            v = make_double2(A.y, B.y);
-        } else {
-            const cplx A = s0[m], B = s1[m];
-            v = make_double2(A.x + B.y, -A.y + B.x);
-        }
+        const cplx A = s0[m == W / 2 ? 0 : m], B = s1[m == W / 2 ? 0 : m];
+        v = m == W / 2 ? make_double2(A.y, B.y) : make_double2(A.x + B.y, -A.y + B.x);
     }
-    tmp[pair * W + idx] = v;
+    tmp[pair * W + (int64_t)(j % RW) * WS + j / RW] = v;
 }
 
 // tmp[pair][q][n] (inverse sub-line transforms done) -> rows 2 pair, 2 pair + 1 of out = alpha * value
@@ -159,6 +154,7 @@ hipError_t rowstep(int R, cplx* spec, int64_t ld, int HS, int ncols, const cplx*
     case 2: hipLaunchKernelGGL((rowstep_kernel<2, INV>), grid, dim3(256), 0, st, spec, ld, HS, ncols, twH); break;
     case 4: hipLaunchKernelGGL((rowstep_kernel<4, INV>), grid, dim3(256), 0, st, spec, ld, HS, ncols, twH); break;
     case 8: hipLaunchKernelGGL((rowstep_kernel<8, INV>), grid, dim3(256), 0, st, spec, ld, HS, ncols, twH); break;
+    case 16: hipLaunchKernelGGL((rowstep_kernel<16, INV>), grid, dim3(256), 0, st, spec, ld, HS, ncols, twH); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -185,12 +185,18 @@ int gpt_long_row_split_radix(int W) {
     if (!pow2_between(W, 256, 32768)) return -1;
     return (W > 16384 || W >= long_min()) ? gpt_long_row_radix() : 0;
 }
-// ... and for a column of H points: the smallest radix that leaves sub-lines of at most 4096 points
+// ... and for a column of H points: sub-lines of GPT_LONG_HS points (4096, or 2048: two workgroups per CU in the
+// sub-line column kernel but a radix-16 step; measured 47.1 ms against 42.5 ms per 32768^2 evaluation on one GPU)
 int gpt_long_col_split_radix(int H) {
     if (!pow2_between(H, 256, 32768)) return -1;
     if (H >= long_min()) return 8;
     if (H <= 8192) return 0;
-    return H / 4096;
+    static const int hs = [] {
+        const char* e = getenv("GPT_LONG_HS");
+        const int v = e ? atoi(e) : 4096;
+        return (v == 2048 || v == 4096) ? v : 4096;
+    }();
+    return H / hs;
 }
 bool gpt_slab_supported(int H, int W) { return gpt_long_row_split_radix(W) >= 0 && gpt_long_col_split_radix(H) >= 0; }
 // complex scratch elements the long-row passes need for `rows` rows of width W (0: none)

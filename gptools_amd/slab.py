@@ -55,6 +55,22 @@ class HipStages:
         return out
 
 
+    def whole_lattice(self, y, loc, cov, out_cov, height, width, alpha):
+        """All three passes on one device (world size 1): no exchange, and the spectrum rows are padded by 8 columns
+        so that the column pass does not walk a power-of-two stride."""
+        ld = width // 2 + 8
+        spec = torch.empty(height, ld, dtype=torch.complex128, device=y.device)
+        lp = torch.empty(1, dtype=torch.float64, device=y.device)
+        mn = torch.empty(1, dtype=torch.float64, device=y.device)
+        out = torch.empty(height, width, dtype=torch.float64, device=y.device)
+        ctx = _fft.get_context(y.device)
+        ctx.call("gpt_slab_rows_fwd", _fft._p(y), _fft._p(loc), height, height, width, _fft._p(spec), ld)
+        ctx.call("gpt_slab_cols_lpdf_vjp", _fft._p(spec), ld, _fft._p(cov), _fft._p(out_cov), height, width, 0,
+                 width // 2, _fft._p(lp), _fft._p(mn))
+        ctx.call("gpt_slab_rows_inv", _fft._p(spec), ld, height, height, width, float(alpha), _fft._p(out))
+        return lp, out, mn
+
+
 class DistComm:
     """Exchanges over a torch.distributed process group (nccl = RCCL on the GPUs, gloo on CPU)."""
 
@@ -157,6 +173,10 @@ def gp_rfft2_lpdf_vjp_slab(y_rows, loc_rows, cov_rfft2, height, width, comm=None
     if tuple(cov_rfft2.shape) != (height, width // 2 + 1):
         raise ValueError("cov_rfft2 keeps the lattice's own (height, width / 2 + 1) layout on every rank")
     n = height * width
+    if world == 1 and isinstance(stages, HipStages):
+        lp, grad_rows, mn = stages.whole_lattice(y_rows.contiguous(), loc_rows.contiguous(), cov_rfft2.contiguous(),
+                                                 out_cov, height, width, -1.0 / n)
+        return (lp - 0.5 * n * math.log(2.0 * math.pi)).reshape(()), grad_rows, mn.reshape(())
     # rows -> packed half spectrum of my rows, cut into the column blocks of the ranks
     spec = stages.rows_fwd(y_rows.contiguous(), loc_rows.contiguous(), height, width)      # (rows, W')
     send = spec.view(rows, world, nc).permute(1, 0, 2).contiguous()                       # (G, rows, nc)
