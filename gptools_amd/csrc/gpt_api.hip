@@ -24,6 +24,8 @@ struct gpt_ctx {
     size_t sink_bytes = 0;
     double* kscr = nullptr; // kernel-fused log density: per-lattice sums, or the spectrum + d/dcov of the fallback
     size_t kscr_bytes = 0;
+    double* oscr = nullptr; // observation models: f, d/df and per-lattice sums when the caller does not keep them
+    size_t oscr_bytes = 0;
     cplx* ltmp = nullptr; // scratch lines of the long-row passes (gpt_long.hip)
     size_t ltmp_bytes = 0;
     char* arena = nullptr; // device staging arena of the host-pointer entry points
@@ -310,6 +312,7 @@ int gpt_destroy(gpt_ctx* c) {
     if (c->arena) (void)hipFree(c->arena);
     if (c->ltmp) (void)hipFree(c->ltmp);
     if (c->kscr) (void)hipFree(c->kscr);
+    if (c->oscr) (void)hipFree(c->oscr);
     if (c->sink) (void)hipFree(c->sink);
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
@@ -732,6 +735,78 @@ int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx* c, int matern, double nu, const double
                                nullptr)) != GPT_OK)
                 return rc;
         }
+    }
+    return GPT_OK;
+}
+
+// Non-centred model density: f = gp_inv_rfft2(z, loc, cov) (fft2.stan:126-130), the observation
+// model of the docs workloads on the device (gpt_obs.hip), the reverse mode of the transform, and optionally the
+// white-noise prior of trees.stan:37. Three transforms' worth of passes + two streaming kernels; f and d/df never
+// leave HBM.
+int gpt_gp_inv_rfft2_obs_lpdf_vjp(gpt_ctx* c, int family, const double* z, int64_t z_bs, const double* loc,
+                                  int64_t loc_bs, const double* cov, int64_t cov_bs, const double* obs, int64_t obs_bs,
+                                  int64_t oh, int64_t ow, const double* theta, int prior, int64_t H, int64_t W,
+                                  int64_t batch, int dim1, double* lp, double* f_out, double* grad_z, double* grad_loc,
+                                  double* grad_loc_sum, double* grad_cov, double* grad_theta, double* min_eig) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    if (!z || !cov || !obs || !lp || !grad_z) return fail(c, GPT_ERR_SHAPE, "z, cov, obs, lp and grad_z must not be null");
+    if (family != GPT_OBS_NORMAL && family != GPT_OBS_POISSON_LOG && family != GPT_OBS_NEG_BINOMIAL_2_LOG)
+        return fail(c, GPT_ERR_SHAPE, "unknown observation family");
+    if (family != GPT_OBS_POISSON_LOG && !theta) return fail(c, GPT_ERR_SHAPE, "this observation family needs theta");
+    if (oh < 1 || ow < 1 || oh > H || ow > W)
+        return fail(c, GPT_ERR_SHAPE, "the observed window must lie inside the lattice");
+    if (batch == 0) return GPT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int64_t hw = H * W, hwf = H * (W / 2 + 1);
+    // lattices per round: library-owned f / d/df of <= ~1 GiB together
+    int64_t chunk = (int64_t)((size_t)(1u << 30) / (16 * (size_t)hw));
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    if (chunk > 32768) chunk = 32768;
+    const size_t nscr = (f_out ? 0 : (size_t)chunk * hw) + (grad_loc ? 0 : (size_t)chunk * hw) + 5 * (size_t)chunk;
+    if ((rc = ensure(c, c->oscr, c->oscr_bytes, sizeof(double) * nscr)) != GPT_OK) return rc;
+    const int nblk = gpt_obs_blocks((int)H, (int)W);
+    double* sums = c->oscr;
+    double* psum = sums + 4 * chunk;
+    double* scr = psum + chunk;
+    double* f_scr = f_out ? nullptr : scr;
+    double* g_scr = grad_loc ? nullptr : scr + (f_out ? 0 : (size_t)chunk * hw);
+    for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
+        const int64_t nb = batch - b0 < chunk ? batch - b0 : chunk;
+        double* f = f_out ? f_out + b0 * hw : f_scr;
+        double* fbar = grad_loc ? grad_loc + b0 * hw : g_scr;
+        const double* zb = z + b0 * z_bs;
+        const double* cb = cov + b0 * cov_bs;
+        if ((rc = gpt_gp_inv_rfft2(c, zb, z_bs, loc ? loc + b0 * loc_bs : nullptr, loc_bs, cb, cov_bs, H, W, nb, dim1, f,
+                                   min_eig ? min_eig + b0 : nullptr)) != GPT_OK)
+            return rc;
+        if ((rc = ensure(c, c->partials, c->partials_bytes, sizeof(double) * GPT_PART * (size_t)nblk * (size_t)nb)) != GPT_OK)
+            return rc;
+        ObsArgs o;
+        memset(&o, 0, sizeof o);
+        o.H = (int)H; o.W = (int)W; o.oh = (int)oh; o.ow = (int)ow; o.family = family;
+        o.batch = nb;
+        o.f = f;
+        o.obs = obs + b0 * obs_bs; o.obs_bs = obs_bs;
+        o.theta = theta ? theta + b0 : nullptr;
+        o.fbar = fbar;
+        HIP_TRY(c, gpt_launch_obs(o, c->partials, c->stream));
+        HIP_TRY(c, gpt_launch_finalize(c->partials, nblk, nb, 4, 0.0, sums, nullptr, c->stream));
+        if ((rc = gpt_gp_inv_rfft2_vjp(c, zb, z_bs, cb, cov_bs, fbar, hw, H, W, nb, dim1, grad_z + b0 * hw,
+                                       grad_cov ? grad_cov + b0 * hwf : nullptr)) != GPT_OK)
+            return rc;
+        if (prior) {
+            // the passes above may have regrown the partials
+            if ((rc = ensure(c, c->partials, c->partials_bytes, sizeof(double) * GPT_PART * (size_t)nblk * (size_t)nb)) !=
+                GPT_OK)
+                return rc;
+            HIP_TRY(c, gpt_launch_prior(zb, z_bs, grad_z + b0 * hw, (int)H, (int)W, nb, c->partials, c->stream));
+            HIP_TRY(c, gpt_launch_finalize(c->partials, nblk, nb, 1, -0.5 * (double)hw * std::log(2.0 * M_PI), psum, nullptr,
+                                           c->stream));
+        }
+        HIP_TRY(c, gpt_launch_obs_combine(sums, prior ? psum : nullptr, nb, lp + b0, grad_theta ? grad_theta + b0 : nullptr,
+                                          grad_loc_sum ? grad_loc_sum + b0 : nullptr, nullptr, c->stream));
     }
     return GPT_OK;
 }

@@ -136,6 +136,37 @@ __device__ __forceinline__ void block_sum_min(double& s, double& m, double* red)
     }
 }
 
+#ifndef GPT_PART
+#define GPT_PART 8 // doubles per workgroup partial (gpt_host.h)
+#endif
+// block-level reduction of K sums + one min into partials[(b * nblk + blk) * GPT_PART + ...]
+template <int K>
+__device__ __forceinline__ void block_reduce_store(double (&s)[K], double mn, double* partials, int64_t b) {
+    __shared__ double red[(K + 1) * 16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = wave_sum(s[k]);
+    mn = wave_min(mn);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) red[k * 16 + w] = s[k];
+        red[K * 16 + w] = mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* p = partials + (b * gridDim.x + blockIdx.x) * GPT_PART;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double t = 0.0;
+            for (int i = 0; i < nw; ++i) t += red[k * 16 + i];
+            p[k] = t;
+        }
+        double m = INFINITY;
+        for (int i = 0; i < nw; ++i) m = fmin(m, red[K * 16 + i]);
+        p[5] = m;
+    }
+}
+
 // Second reduction stage folded into a later kernel of the same stream: one workgroup sums the per-workgroup
 // partials of lattice b (slot 0 = log-density terms, slot 5 = min of the scaled spectrum) in a fixed order.
 // Every thread of the workgroup must call it; `red` is LDS scratch of 2 * (blockDim.x / 64) doubles.

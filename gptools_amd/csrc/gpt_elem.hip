@@ -17,34 +17,6 @@ __device__ __forceinline__ int entry_kind(int H, int W, int i, int j) {
     return (i <= (H - 1) / 2) ? 2 : 0;
 }
 
-// block-level reduction of K sums + one min into partials[(b * nblk + blk) * GPT_PART + ...]
-template <int K>
-__device__ __forceinline__ void block_reduce_store(double (&s)[K], double mn, double* partials, int64_t b) {
-    __shared__ double red[(K + 1) * 16];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-    for (int k = 0; k < K; ++k) s[k] = wave_sum(s[k]);
-    mn = wave_min(mn);
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) red[k * 16 + w] = s[k];
-        red[K * 16 + w] = mn;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double* p = partials + (b * gridDim.x + blockIdx.x) * GPT_PART;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            double t = 0.0;
-            for (int i = 0; i < nw; ++i) t += red[k * 16 + i];
-            p[k] = t;
-        }
-        double m = INFINITY;
-        for (int i = 0; i < nw; ++i) m = fmin(m, red[K * 16 + i]);
-        p[5] = m;
-    }
-}
-
 __global__ void __launch_bounds__(256) scale_kernel(ElemArgs e, double* partials) {
     const int64_t b = blockIdx.y;
     const int Wf = e.W / 2 + 1;

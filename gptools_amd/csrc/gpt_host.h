@@ -84,3 +84,22 @@ hipError_t gpt_launch_kvjp_combine(const double* ksums, const double* params, in
                                    double* params_bar, hipStream_t st);
 // Row-major <-> column-major (Stan/Eigen) transposes of a batch of R x C matrices of `esz`-byte elements.
 hipError_t gpt_launch_transpose(const void* in, void* out, int R, int C, int64_t batch, int esz, hipStream_t st);
+
+// --- observation models on the latent field (gpt_obs.hip); families as in include/gptools_hip.h
+struct ObsArgs {
+    int H, W, oh, ow, family;
+    int64_t batch;
+    const double* f;     // [batch][H][W]
+    const double* obs;   // [batch][oh][ow], obs_bs elements apart (0 = shared)
+    int64_t obs_bs;
+    const double* theta; // [batch] or null
+    double* fbar;        // [batch][H][W]
+};
+// partials: batch * gpt_obs_blocks(H, W) * GPT_PART doubles; slots 0..3 = log density, d/dtheta, sum of d/df, points
+int gpt_obs_blocks(int H, int W);
+hipError_t gpt_launch_obs(const ObsArgs& a, double* partials, hipStream_t st);
+// zbar -= z; slot 0 = -sum z^2 / 2
+hipError_t gpt_launch_prior(const double* z, int64_t z_bs, double* zbar, int H, int W, int64_t batch, double* partials,
+                            hipStream_t st);
+hipError_t gpt_launch_obs_combine(const double* sums, const double* psum, int64_t batch, double* lp, double* grad_theta,
+                                  double* grad_loc_sum, double* nobs, hipStream_t st);

@@ -1,0 +1,170 @@
+// Observation models on the device: the docs models of the reference draw the latent field
+// with the non-centred parameterisation, f = gp_inv_rfft2(z, loc, cov), and then score data against f inside Stan:
+//     docs/trees/trees.stan:43-49          frequency[i, j] ~ neg_binomial_2(exp(f[i, j]), 1 / kappa), masked where < 0,
+//                                          on the num_rows x num_cols corner of the padded lattice
+//     docs/padding/padded.stan:34          y[:observe_first] ~ normal(f[:observe_first], kappa)
+//     docs/poisson_regression/poisson_regression_fourier_non_centered.stan:26     y ~ poisson_log(eta)
+// With these kernels f and df never cross PCIe: one streaming pass reads f and the data, writes d lp / d f for the
+// whole (padded) lattice and reduces the log density and the derivative with respect to the family's parameter.
+// HBM-bound: 8 bytes read + 8 written per lattice point, + 8 read per observed point.
+#include "../../include/gptools_hip.h"
+#include "gpt_common.h"
+#include "gpt_host.h"
+
+namespace {
+
+constexpr double HALF_LOG_2PI = 0.91893853320467274178;
+
+// digamma(x), x > 0: recurrence up to x >= 10, then the asymptotic series (next term < 5e-17)
+__device__ __forceinline__ double digamma_pos(double x) {
+    double r = 0.0;
+    while (x < 10.0) {
+        r -= 1.0 / x;
+        x += 1.0;
+    }
+    const double i = 1.0 / x, i2 = i * i;
+    const double ser =
+        i2 * (1.0 / 12 - i2 * (1.0 / 120 - i2 * (1.0 / 252 - i2 * (1.0 / 240 - i2 * (1.0 / 132 - i2 * (691.0 / 32760 - i2 / 12))))));
+    return r + log(x) - 0.5 * i - ser;
+}
+
+// log(exp(a) + exp(b))
+__device__ __forceinline__ double log_sum_exp2(double a, double b) {
+    const double m = fmax(a, b);
+    return m + log1p(exp(-fabs(a - b)));
+}
+
+struct ObsTerm {
+    double lp, df, dth;
+};
+
+// one observed point. FAM: GPT_OBS_NORMAL (theta = standard deviation), GPT_OBS_POISSON_LOG (no parameter),
+// GPT_OBS_NEG_BINOMIAL_2_LOG (theta = precision phi; mean exp(f)). All normalising constants are kept, as in
+// gp_rfft2_lpdf (fft2.stan:189-192).
+template <int FAM> __device__ __forceinline__ ObsTerm obs_term(double y, double f, double th, const double* k) {
+    ObsTerm t;
+    if (FAM == GPT_OBS_NORMAL) {
+        // k[0] = 1 / theta, k[1] = log(theta)
+        const double r = (y - f) * k[0];
+        t.lp = -0.5 * r * r - k[1] - HALF_LOG_2PI;
+        t.df = r * k[0];
+        t.dth = (r * r - 1.0) * k[0];
+    } else if (FAM == GPT_OBS_POISSON_LOG) {
+        const double mu = exp(f);
+        t.lp = y * f - mu - lgamma(y + 1.0);
+        t.df = y - mu;
+        t.dth = 0.0;
+    } else {
+        // k[0] = log(phi), k[1] = lgamma(phi), k[2] = digamma(phi)
+        const double lse = log_sum_exp2(f, k[0]); // log(mu + phi)
+        const double npf = y + th;
+        t.lp = lgamma(npf) - lgamma(y + 1.0) - k[1] + y * (f - lse) + th * (k[0] - lse);
+        t.df = y - npf * exp(f - lse);
+        t.dth = digamma_pos(npf) - k[2] + k[0] - lse + 1.0 - npf * exp(-lse);
+    }
+    return t;
+}
+
+template <int FAM> __global__ void __launch_bounds__(256) obs_kernel(ObsArgs a, double* partials) {
+    const int64_t b = blockIdx.y;
+    const int64_t tot = (int64_t)a.H * a.W;
+    const double* f = a.f + b * tot;
+    const double* y = a.obs + b * a.obs_bs;
+    double* fb = a.fbar + b * tot;
+    const double th = a.theta ? a.theta[b] : 0.0;
+    double k[3] = {0.0, 0.0, 0.0};
+    if (FAM == GPT_OBS_NORMAL) {
+        k[0] = 1.0 / th;
+        k[1] = log(th);
+    } else if (FAM == GPT_OBS_NEG_BINOMIAL_2_LOG) {
+        k[0] = log(th);
+        k[1] = lgamma(th);
+        k[2] = digamma_pos(th);
+    }
+    double s[4] = {0.0, 0.0, 0.0, 0.0}; // log density, d/dtheta, sum of d/df, observed points
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < tot; w += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(w / a.W), j = (int)(w - (int64_t)i * a.W);
+        double g = 0.0;
+        if (i < a.oh && j < a.ow) {
+            const double yv = y[(int64_t)i * a.ow + j];
+            // masked: NaN for every family; negative counts (trees.stan:45)
+            const bool seen = yv == yv && (FAM == GPT_OBS_NORMAL || yv >= 0.0);
+            if (seen) {
+                const ObsTerm t = obs_term<FAM>(yv, f[w], th, k);
+                g = t.df;
+                s[0] += t.lp;
+                s[1] += t.dth;
+                s[2] += t.df;
+                s[3] += 1.0;
+            }
+        }
+        fb[w] = g;
+    }
+    block_reduce_store<4>(s, INFINITY, partials, b);
+}
+
+// z ~ std_normal() (trees.stan:37): zbar -= z, partial sums of -z^2 / 2
+__global__ void __launch_bounds__(256) prior_kernel(const double* __restrict__ z, int64_t z_bs, double* __restrict__ zbar,
+                                                    int64_t tot, double* partials) {
+    const int64_t b = blockIdx.y;
+    const double* zb = z + b * z_bs;
+    double* o = zbar + b * tot;
+    double s[1] = {0.0};
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < tot; w += (int64_t)gridDim.x * blockDim.x) {
+        const double v = zb[w];
+        o[w] -= v;
+        s[0] -= 0.5 * v * v;
+    }
+    block_reduce_store<1>(s, INFINITY, partials, b);
+}
+
+__global__ void obs_combine_kernel(const double* sums, const double* psum, int64_t batch, double* lp, double* grad_theta,
+                                   double* grad_loc_sum, double* nobs) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    if (lp) lp[b] = sums[4 * b] + (psum ? psum[b] : 0.0);
+    if (grad_theta) grad_theta[b] = sums[4 * b + 1];
+    if (grad_loc_sum) grad_loc_sum[b] = sums[4 * b + 2];
+    if (nobs) nobs[b] = sums[4 * b + 3];
+}
+
+} // namespace
+
+int gpt_obs_blocks(int H, int W) {
+    int64_t nb = ((int64_t)H * W + 1023) / 1024;
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;
+    return (int)nb;
+}
+
+hipError_t gpt_launch_obs(const ObsArgs& a, double* partials, hipStream_t st) {
+    if (a.batch <= 0) return hipSuccess;
+    if (a.batch > 65535) return hipErrorInvalidValue; // callers chunk the batch
+    dim3 grid((unsigned)gpt_obs_blocks(a.H, a.W), (unsigned)a.batch), block(256);
+    switch (a.family) {
+    case GPT_OBS_NORMAL: hipLaunchKernelGGL(obs_kernel<GPT_OBS_NORMAL>, grid, block, 0, st, a, partials); break;
+    case GPT_OBS_POISSON_LOG: hipLaunchKernelGGL(obs_kernel<GPT_OBS_POISSON_LOG>, grid, block, 0, st, a, partials); break;
+    case GPT_OBS_NEG_BINOMIAL_2_LOG:
+        hipLaunchKernelGGL(obs_kernel<GPT_OBS_NEG_BINOMIAL_2_LOG>, grid, block, 0, st, a, partials);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t gpt_launch_prior(const double* z, int64_t z_bs, double* zbar, int H, int W, int64_t batch, double* partials,
+                            hipStream_t st) {
+    if (batch <= 0) return hipSuccess;
+    if (batch > 65535) return hipErrorInvalidValue;
+    dim3 grid((unsigned)gpt_obs_blocks(H, W), (unsigned)batch), block(256);
+    hipLaunchKernelGGL(prior_kernel, grid, block, 0, st, z, z_bs, zbar, (int64_t)H * W, partials);
+    return hipGetLastError();
+}
+
+hipError_t gpt_launch_obs_combine(const double* sums, const double* psum, int64_t batch, double* lp, double* grad_theta,
+                                  double* grad_loc_sum, double* nobs, hipStream_t st) {
+    if (batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(obs_combine_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, sums, psum, batch, lp,
+                       grad_theta, grad_loc_sum, nobs);
+    return hipGetLastError();
+}

@@ -15,6 +15,7 @@ import ctypes
 import math
 import threading
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -91,7 +92,9 @@ def _p(t):
 
 def _dev(x, like=None):
     if not isinstance(x, torch.Tensor):
-        x = torch.as_tensor(x)
+        # through numpy: torch.as_tensor would round Python floats to float32
+        a = np.asarray(x)
+        x = torch.as_tensor(a if np.iscomplexobj(a) else a.astype(np.float64, copy=False))
     if x.dtype not in (torch.float64, torch.complex128):
         x = x.to(torch.complex128 if x.is_complex() else torch.float64)
     if not x.is_cuda:
@@ -425,6 +428,51 @@ def gp_rfft_vjp(y, loc, cov_rfft, zbar):
 def gp_rfft2_vjp(y, loc, cov_rfft2, zbar):
     """Reverse mode of fft2.stan:112-114: ``zbar -> (ybar, covbar)``; ``locbar = -ybar``."""
     return _fwd_vjp(y, loc, cov_rfft2, zbar, False)
+
+
+# ---- observation models on the latent field (SURVEY 8(f) rank 3) ----------------------------------
+OBS_FAMILIES = {"normal": 0, "poisson_log": 1, "neg_binomial_2_log": 2}
+
+
+def _obs_lpdf_vjp(family, z, loc, cov, obs, theta, prior, dim1, check, need_cov_grad):
+    g = _prep(z, loc, cov, dim1)
+    core = 1 if dim1 else 2
+    obs = _dev(obs, g["main"])
+    obs, _, o_bs = _batched(obs, core, g["bshape"])
+    oh = 1 if dim1 else obs.shape[-2]
+    ow = obs.shape[-1]
+    fam = OBS_FAMILIES[family]
+    th = None
+    if fam != 1:
+        if theta is None:
+            raise ValueError(f"the {family} family needs theta")
+        th = _dev(theta, g["main"]).expand(g["bshape"]).contiguous()
+    lp, mn, gls = _new(g), _new(g), _new(g)
+    gth = _new(g) if th is not None else None
+    f = torch.empty_like(g["main"])
+    gz = torch.empty_like(g["main"])
+    gl = torch.empty_like(g["main"])
+    gc = _new(g, *((g["Wf"],) if dim1 else (g["H"], g["Wf"]))) if need_cov_grad else None
+    get_context(lp.device).call("gpt_gp_inv_rfft2_obs_lpdf_vjp", fam, _p(g["main"]), g["m_bs"], _p(g["loc"]), g["l_bs"],
+                                _p(g["cov"]), g["c_bs"], _p(obs), o_bs, oh, ow, _p(th), int(bool(prior)), g["H"], g["W"],
+                                g["B"], g["dim1"], _p(lp), _p(f), _p(gz), _p(gl), _p(gls), _p(gc), _p(gth), _p(mn))
+    _check_pd(mn, check)
+    return dict(lp=lp, f=f, grad_z=gz, grad_loc=gl, grad_loc_sum=gls, grad_cov=gc, grad_theta=gth)
+
+
+def gp_inv_rfft2_obs_lpdf_vjp(family, z, loc, cov_rfft2, obs, theta=None, prior=True, check=True, need_cov_grad=True):
+    """Log density and gradients of a non-centred docs model on the device: ``f = gp_inv_rfft2(z, loc, cov)``
+    (fft2.stan:126-130), ``lp = sum family_lpdf(obs | f, theta) [+ std_normal_lpdf(z)]`` over the ``obs`` corner of the
+    (padded) lattice, NaN / negative counts masked (docs/trees/trees.stan:31-49). ``family``: ``"normal"`` (theta =
+    standard deviation), ``"poisson_log"``, ``"neg_binomial_2_log"`` (theta = precision; trees.stan passes 1/kappa).
+    Returns a dict: ``lp, f, grad_z, grad_loc`` (= d lp / d f), ``grad_loc_sum, grad_cov, grad_theta``."""
+    return _obs_lpdf_vjp(family, z, loc, cov_rfft2, obs, theta, prior, False, check, need_cov_grad)
+
+
+def gp_inv_rfft_obs_lpdf_vjp(family, z, loc, cov_rfft, obs, theta=None, prior=True, check=True, need_cov_grad=True):
+    """1-D sibling: docs/padding/padded.stan:29-34 (``obs = y[:observe_first]``),
+    docs/poisson_regression/poisson_regression_fourier_non_centered.stan:20-26."""
+    return _obs_lpdf_vjp(family, z, loc, cov_rfft, obs, theta, prior, True, check, need_cov_grad)
 
 
 # ---- spectral kernels ------------------------------------------------------------------------------

@@ -200,6 +200,27 @@ int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx*, int matern, double nu, const double* 
                                  int64_t batch, int dim1, double* lpdf, double* grad_y, double* params_bar,
                                  double* min_eig);
 
+/* Observation models on the device. In the reference the docs models score data against the
+ * latent field inside Stan, after f = gp_inv_rfft2(z, loc, cov) (fft2.stan:126-130):
+ *   docs/trees/trees.stan:37,43-49 (neg_binomial_2(exp(f), 1/kappa) on the unpadded corner, negative counts masked),
+ *   docs/padding/padded.stan:33-34 (normal(f[:observe_first], kappa)),
+ *   docs/poisson_regression/poisson_regression_fourier_non_centered.stan:25-26 (poisson_log(eta)).
+ * One call evaluates, per lattice b,
+ *   lp[b] = sum over the obs_h x obs_w corner, unmasked points, of family_lpdf(obs[i,j] | f[i,j], theta[b])
+ *           (+ std_normal_lpdf(z[b]) when `prior` is non-zero),
+ * all normalising constants included, and its reverse mode: grad_z, grad_cov (may be NULL), grad_loc (= d lp / d f
+ * over the whole lattice, zero where nothing is observed; may be NULL), grad_loc_sum[b] (the derivative with respect to
+ * a scalar loc as in trees.stan:32; may be NULL), grad_theta[b] (may be NULL). f_out (may be NULL) receives f.
+ * `obs` is [batch][obs_h][obs_w] doubles (obs_bs elements apart, 0 = shared), counts stored as doubles; a NaN, or a
+ * negative count, is a masked point. theta: GPT_OBS_NORMAL standard deviation, GPT_OBS_NEG_BINOMIAL_2_LOG precision phi
+ * (trees.stan passes 1 / kappa), GPT_OBS_POISSON_LOG none (NULL). f and d/df stay in HBM between the three steps. */
+enum { GPT_OBS_NORMAL = 0, GPT_OBS_POISSON_LOG = 1, GPT_OBS_NEG_BINOMIAL_2_LOG = 2 };
+int gpt_gp_inv_rfft2_obs_lpdf_vjp(gpt_ctx*, int family, const double* z, int64_t z_bs, const double* loc, int64_t loc_bs,
+                                  const double* cov, int64_t cov_bs, const double* obs, int64_t obs_bs, int64_t obs_h,
+                                  int64_t obs_w, const double* theta, int prior, int64_t height, int64_t width,
+                                  int64_t batch, int dim1, double* lp, double* f_out, double* grad_z, double* grad_loc,
+                                  double* grad_loc_sum, double* grad_cov, double* grad_theta, double* min_eig);
+
 /* ---- host-pointer entry points (what the Stan user header binds) ----------------
  * One lattice per call (batch == 1), `layout` as above. Matrices are height x width (cov: height x
  * (width/2+1)). */

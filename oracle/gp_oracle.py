@@ -599,3 +599,85 @@ def gp_rfft2_vjp(y, loc, cov_rfft2, zbar):
     #   = n * irfft2(Dh): a pair entry stands for two full-spectrum slots (hence the 1/2 above).
     ybar = height * width * inv_rfft2(Dh, width)
     return ybar, -ybar, cbar
+
+
+# ---------------------------------------------------------------------------------------------------
+# Observation models of the docs workloads on the latent field
+# ---------------------------------------------------------------------------------------------------
+# The densities are Stan Math's (third party, cmdstan 2.36.0; not in the reference checkout): their published
+# definitions are restated here with scipy.special. Call sites in the reference: docs/trees/trees.stan:46
+# (neg_binomial_2), docs/padding/padded.stan:34 (normal),
+# docs/poisson_regression/poisson_regression_fourier_non_centered.stan:26 (poisson_log). Pinned against
+# scipy.stats and fp64 autograd in tests/test_oracle_obs.py; the reference holds no fixtures for them
+# (its tests only check that the docs models run: python/stan/tests/test_examples.py).
+
+OBS_NORMAL, OBS_POISSON_LOG, OBS_NEG_BINOMIAL_2_LOG = 0, 1, 2
+
+
+def obs_lpdf_vjp(family, obs, f, theta=None):
+    """Sum over the observed corner of ``family_lpdf(obs | f, theta)`` with d/df (zero where unobserved) and d/dtheta.
+
+    ``obs`` is ``(..., h, w)`` with ``h <= H``, ``w <= W`` (the unpadded corner, trees.stan:43-44); NaN, and for the
+    count families a negative value (trees.stan:45), masks a point. ``theta`` has the batch shape.
+    """
+    f = np.asarray(f, dtype=np.float64)
+    obs = np.asarray(obs, dtype=np.float64)
+    oh, ow = obs.shape[-2:]
+    bshape = f.shape[:-2]
+    y = np.broadcast_to(obs, bshape + (oh, ow))
+    fw = f[..., :oh, :ow]
+    seen = ~np.isnan(y)
+    if family != OBS_NORMAL:
+        seen &= ~(y < 0)
+    ys = np.where(seen, y, 0.0)
+    th = None if theta is None else np.broadcast_to(np.asarray(theta, dtype=np.float64), bshape)[..., None, None]
+    if family == OBS_NORMAL:
+        r = (ys - fw) / th
+        lp = -0.5 * r * r - np.log(th) - 0.5 * LOG2PI
+        df = r / th
+        dth = (r * r - 1.0) / th
+    elif family == OBS_POISSON_LOG:
+        mu = np.exp(fw)
+        lp = ys * fw - mu - special.gammaln(ys + 1.0)
+        df = ys - mu
+        dth = np.zeros_like(fw)
+    elif family == OBS_NEG_BINOMIAL_2_LOG:
+        # neg_binomial_2(n | mu = exp(f), phi): lchoose(n + phi - 1, n) + n log(mu / (mu + phi)) + phi log(phi / (mu + phi))
+        lphi = np.log(th)
+        lse = np.logaddexp(fw, lphi)
+        lp = (special.gammaln(ys + th) - special.gammaln(ys + 1.0) - special.gammaln(th) + ys * (fw - lse)
+              + th * (lphi - lse))
+        df = ys - (ys + th) * np.exp(fw - lse)
+        dth = special.digamma(ys + th) - special.digamma(th) + lphi - lse + 1.0 - (ys + th) * np.exp(-lse)
+    else:
+        raise ValueError(f"unknown observation family {family}")
+    fbar = np.zeros_like(f)
+    fbar[..., :oh, :ow] = np.where(seen, df, 0.0)
+    return np.where(seen, lp, 0.0).sum(axis=(-2, -1)), fbar, np.where(seen, dth, 0.0).sum(axis=(-2, -1))
+
+
+def gp_inv_rfft2_obs_lpdf_vjp(family, z, loc, cov_rfft2, obs, theta=None, prior=True):
+    """Log density of a non-centred docs model and its gradients (trees.stan:31-49 without the scalar priors):
+    ``f = gp_inv_rfft2(z, loc, cov)``; ``lp = sum obs_lpdf(obs | f, theta) [+ std_normal_lpdf(z)]``.
+    Returns ``(lp, f, zbar, locbar, locbar_sum, covbar, thetabar)``."""
+    z = np.asarray(z, dtype=np.float64)
+    f = gp_inv_rfft2(z, loc, cov_rfft2)
+    lp, fbar, thbar = obs_lpdf_vjp(family, obs, f, theta)
+    zbar, locbar, cbar = gp_inv_rfft2_vjp(z, loc, cov_rfft2, fbar)
+    if prior:
+        lp = lp + std_normal_lpdf(z, (-2, -1))
+        zbar = zbar - z
+    return lp, f, zbar, locbar, locbar.sum(axis=(-2, -1)), cbar, thbar
+
+
+def gp_inv_rfft_obs_lpdf_vjp(family, z, loc, cov_rfft, obs, theta=None, prior=True):
+    """1-D sibling (padded.stan:29-34, poisson_regression_fourier_non_centered.stan:20-26)."""
+    z = np.asarray(z, dtype=np.float64)
+    f = gp_inv_rfft(z, loc, cov_rfft)
+    lp, fbar, thbar = obs_lpdf_vjp(family, np.asarray(obs, dtype=np.float64)[..., None, :], f[..., None, :], theta)
+    fbar = fbar[..., 0, :]
+    zbar, locbar, cbar = gp_inv_rfft_vjp(z, loc, cov_rfft, fbar)
+    if prior:
+        lp = lp + std_normal_lpdf(z, (-1,))
+        zbar = zbar - z
+    return lp, f, zbar, locbar, locbar.sum(axis=-1), cbar, thbar

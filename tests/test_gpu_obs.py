@@ -1,0 +1,159 @@
+"""
+GPU parity of the on-device observation models (docs/trees/trees.stan:31-49,
+docs/padding/padded.stan:29-34, docs/poisson_regression/poisson_regression_fourier_non_centered.stan:20-26):
+gpt_gp_inv_rfft2_obs_lpdf_vjp through the C ABI against the CPU oracle on the same seeded inputs. Tolerance: relative
+1e-10 on the log density and every gradient (fp64), as for the rest of the path.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+import gp_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+FAMILIES = {"normal": o.OBS_NORMAL, "poisson_log": o.OBS_POISSON_LOG, "neg_binomial_2_log": o.OBS_NEG_BINOMIAL_2_LOG}
+
+
+def close(actual, desired, rtol=RTOL):
+    actual = actual.cpu().numpy() if hasattr(actual, "cpu") else np.asarray(actual)
+    desired = np.asarray(desired)
+    s = max(float(np.max(np.abs(desired))), 1e-300)
+    np.testing.assert_allclose(actual, desired, rtol=rtol, atol=rtol * s)
+
+
+@pytest.fixture(scope="module")
+def fft(gpu_lib):
+    from gptools_amd import fft as f
+
+    return f
+
+
+def _data(family, rng, window, batch):
+    if family == "normal":
+        obs = rng.normal(size=window)
+        theta = rng.gamma(4.0, 0.3, size=batch)
+    else:
+        obs = rng.poisson(3.0, size=window).astype(float)
+        obs[rng.random(window) < 0.1] = -1.0  # masked quadrats, trees.stan:45
+        theta = rng.gamma(4.0, 0.7, size=batch) if family == "neg_binomial_2_log" else None
+    obs[rng.random(window) < 0.05] = np.nan
+    return obs, theta
+
+
+def _check(res, want, has_theta):
+    lp, f, zbar, locbar, lsum, cbar, thbar = want
+    close(res["lp"], lp)
+    close(res["f"], f)
+    close(res["grad_z"], zbar)
+    close(res["grad_loc"], locbar)
+    close(res["grad_loc_sum"], lsum)
+    close(res["grad_cov"], cbar)
+    if has_theta:
+        close(res["grad_theta"], thbar)
+
+
+# small-lattice path, generic path (odd sizes), power-of-two path; the trees docs shape is 50 x 25 padded to 60 x 35
+@pytest.mark.parametrize("shape,window", [((35, 60), (25, 50)), ((6, 8), (6, 8)), ((7, 9), (3, 4)),
+                                          ((256, 512), (200, 300)), ((300, 210), (150, 210))])
+@pytest.mark.parametrize("family", list(FAMILIES))
+@pytest.mark.parametrize("prior", [True, False])
+def test_obs_lpdf_vjp_2d(fft, family, shape, window, prior):
+    rng = np.random.default_rng(zlib.crc32(repr((family, shape, prior)).encode()))
+    H, W = shape
+    B = 3
+    z = rng.normal(size=(B, H, W))
+    loc = np.full((H, W), 0.4)
+    cov = o.gp_periodic_matern_cov_rfft2(1.5, H, W, 0.9, np.array([2.0, 3.0]), np.array([H, W])) + 1e-3
+    obs, theta = _data(family, rng, window, (B,))
+    want = o.gp_inv_rfft2_obs_lpdf_vjp(FAMILIES[family], z, loc, cov, obs, theta, prior)
+    res = fft.gp_inv_rfft2_obs_lpdf_vjp(family, z, loc, cov, obs, theta, prior)
+    _check(res, want, theta is not None)
+
+
+def test_obs_batched_data_and_cov(fft):
+    """Per-lattice data, spectra and locations (batch strides != 0)."""
+    rng = np.random.default_rng(77)
+    B, H, W = 4, 12, 10
+    z = rng.normal(size=(B, H, W))
+    loc = rng.normal(size=(B, H, W))
+    cov = np.stack([o.gp_periodic_exp_quad_cov_rfft2(H, W, 0.5 + 0.2 * b, np.array([1.5, 2.0]), np.array([H, W])) + 1e-2
+                    for b in range(B)])
+    obs = rng.poisson(2.0, size=(B, 9, 7)).astype(float)
+    theta = rng.gamma(4.0, 0.7, size=B)
+    want = o.gp_inv_rfft2_obs_lpdf_vjp(o.OBS_NEG_BINOMIAL_2_LOG, z, loc, cov, obs, theta, True)
+    res = fft.gp_inv_rfft2_obs_lpdf_vjp("neg_binomial_2_log", z, loc, cov, obs, theta, True)
+    _check(res, want, True)
+
+
+@pytest.mark.parametrize("family", ["normal", "poisson_log"])
+@pytest.mark.parametrize("n,first", [(128, 100), (21, 21), (1024, 700)])
+def test_obs_lpdf_vjp_1d(fft, family, n, first):
+    """padded.stan (normal on a prefix) and the Poisson regression model."""
+    rng = np.random.default_rng(n + first)
+    z = rng.normal(size=(2, n))
+    cov = o.gp_periodic_exp_quad_cov_rfft(n, 1.2, 4.0, n) + 1e-3
+    if family == "normal":
+        y, theta = rng.normal(size=first), np.array([0.7, 1.3])
+    else:
+        y, theta = rng.poisson(2.0, size=first).astype(float), None
+    want = o.gp_inv_rfft_obs_lpdf_vjp(FAMILIES[family], z, np.zeros(n), cov, y, theta, True)
+    res = fft.gp_inv_rfft_obs_lpdf_vjp(family, z, None, cov, y, theta, True)
+    _check(res, want, theta is not None)
+
+
+def test_obs_large_counts_and_extreme_fields(fft):
+    """lgamma / digamma / log-sum-exp branches: counts up to 1e5, fields from -30 to 12, small and large precision."""
+    rng = np.random.default_rng(3)
+    H, W = 8, 8
+    for phi in (1e-3, 0.5, 40.0, 1e5):
+        z = rng.normal(size=(H, W))
+        loc = np.linspace(-30, 12, H * W).reshape(H, W)
+        cov = o.gp_periodic_exp_quad_cov_rfft2(H, W, 0.1, np.array([1.0, 1.0]), np.array([H, W])) + 1e-4
+        obs = np.floor(10 ** rng.uniform(0, 5, size=(H, W)))
+        want = o.gp_inv_rfft2_obs_lpdf_vjp(o.OBS_NEG_BINOMIAL_2_LOG, z, loc, cov, obs, phi, False)
+        res = fft.gp_inv_rfft2_obs_lpdf_vjp("neg_binomial_2_log", z, loc, cov, obs, phi, False)
+        close(res["lp"], want[0])
+        close(res["grad_z"], want[2])
+        close(res["grad_theta"], want[6], rtol=1e-9)
+
+
+def test_obs_full_size_properties(fft):
+    """4096 x 4096 (BASELINE config 4 lattice): size-independent properties instead of the oracle. With every point
+    masked the density is the prior alone and the gradient is -z; with a Poisson likelihood sum(d lp / d f) equals
+    sum(obs - exp(f)) over the window."""
+    import torch
+
+    H = W = 4096
+    g = torch.Generator(device="cuda").manual_seed(1)
+    z = torch.randn(H, W, dtype=torch.float64, device="cuda", generator=g)
+    cov = fft.gp_periodic_matern_cov_rfft2(1.5, H, W, 0.5, [8.0, 12.0], [H, W]) + 1e-3
+    loc = torch.zeros(H, W, dtype=torch.float64, device="cuda")
+    obs = torch.full((3000, 3500), float("nan"), dtype=torch.float64, device="cuda")
+    res = fft.gp_inv_rfft2_obs_lpdf_vjp("poisson_log", z, loc, cov, obs, None, True)
+    want = -0.5 * float((z * z).sum()) - 0.5 * H * W * np.log(2 * np.pi)
+    assert abs(float(res["lp"]) - want) <= 1e-10 * abs(want)
+    assert torch.equal(res["grad_z"], -z)
+    obs = torch.poisson(torch.full((3000, 3500), 2.0, dtype=torch.float64, device="cuda"), generator=g)
+    res = fft.gp_inv_rfft2_obs_lpdf_vjp("poisson_log", z, loc, cov, obs, None, False)
+    f = fft.gp_inv_rfft2(z, loc, cov)
+    assert torch.equal(res["f"], f)
+    fw = f[:3000, :3500]
+    want_sum = float((obs - torch.exp(fw)).sum())
+    assert abs(float(res["grad_loc_sum"]) - want_sum) <= 1e-9 * max(abs(want_sum), float(obs.sum()))
+    want_lp = float((obs * fw - torch.exp(fw) - torch.lgamma(obs + 1)).sum())
+    assert abs(float(res["lp"]) - want_lp) <= 1e-10 * abs(want_lp)
+    # the gradient with respect to z is the reverse mode of the transform applied to d lp / d f
+    zbar, _ = fft.gp_inv_rfft2_vjp(z, cov, res["grad_loc"])
+    assert torch.equal(res["grad_z"], zbar)
+
+
+def test_obs_rejects_bad_arguments(fft):
+    z = np.zeros((4, 6))
+    cov = np.ones((4, 4))
+    with pytest.raises(Exception):
+        fft.gp_inv_rfft2_obs_lpdf_vjp("poisson_log", z, None, cov, np.zeros((5, 6)))  # window taller than the lattice
+    with pytest.raises(ValueError):
+        fft.gp_inv_rfft2_obs_lpdf_vjp("normal", z, None, cov, np.zeros((4, 6)))  # no theta
