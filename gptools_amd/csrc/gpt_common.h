@@ -173,6 +173,16 @@ __device__ __forceinline__ void block_reduce_store(double (&s)[K], double mn, do
 #ifndef GPT_PART
 #define GPT_PART 8 // doubles per workgroup partial (gpt_host.h)
 #endif
+// Observation model fused between the inverse and the forward row transforms (row_obs_kernel, gpt_pow2_impl.h)
+struct ObsRowArgs {
+    int family, oh, ow;  // GPT_OBS_*; observed corner of the lattice
+    const double* obs;   // [batch][oh][ow], obs_bs elements apart (0 = shared)
+    int64_t obs_bs;
+    const double* theta; // [batch] or null
+    double* f_out;       // [batch][H][W] or null
+    double* fbar_out;    // [batch][H][W] or null
+    double* partials;    // [batch][gridDim.x][GPT_PART]: log density, d/dtheta, sum of d/df, observed points
+};
 struct FinArgs {
     const double* partials; // null: nothing to do
     int nblk;

@@ -36,6 +36,14 @@ int gpt_slab_col_blocks(int H, int ncols, int cus);
 hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, int ld, double alpha, double* partials,
                               int cus, cplx* tmp, hipStream_t st);
 
+// Non-centred model density: inverse rows -> observation model -> forward rows in place on the workspace, between
+// pass 1 of OP_GP_INV_RFFT2 and pass 1 of OP_INV_VJP (rows of up to 8192 points). o.partials holds
+// batch * gpt_pow2_obs_blocks(H, W) * GPT_PART doubles.
+bool gpt_pow2_obs_supported(int H, int W);
+int gpt_pow2_obs_blocks(int H, int W);
+hipError_t gpt_pow2_obs_rows(const LatArgs& a, cplx* ws, double* partials, int col_cus, const ObsRowArgs& o,
+                             hipStream_t st);
+
 // --- generic large path (gpt_generic.hip): any H, W whose lines fit LDS
 bool gpt_generic_supported(int H, int W);
 size_t gpt_generic_workspace_bytes(int H, int W);

@@ -10,60 +10,9 @@
 #include "../../include/gptools_hip.h"
 #include "gpt_common.h"
 #include "gpt_host.h"
+#include "gpt_obs_dev.h"
 
 namespace {
-
-constexpr double HALF_LOG_2PI = 0.91893853320467274178;
-
-// digamma(x), x > 0: recurrence up to x >= 10, then the asymptotic series (next term < 5e-17)
-__device__ __forceinline__ double digamma_pos(double x) {
-    double r = 0.0;
-    while (x < 10.0) {
-        r -= 1.0 / x;
-        x += 1.0;
-    }
-    const double i = 1.0 / x, i2 = i * i;
-    const double ser =
-        i2 * (1.0 / 12 - i2 * (1.0 / 120 - i2 * (1.0 / 252 - i2 * (1.0 / 240 - i2 * (1.0 / 132 - i2 * (691.0 / 32760 - i2 / 12))))));
-    return r + log(x) - 0.5 * i - ser;
-}
-
-// log(exp(a) + exp(b))
-__device__ __forceinline__ double log_sum_exp2(double a, double b) {
-    const double m = fmax(a, b);
-    return m + log1p(exp(-fabs(a - b)));
-}
-
-struct ObsTerm {
-    double lp, df, dth;
-};
-
-// one observed point. FAM: GPT_OBS_NORMAL (theta = standard deviation), GPT_OBS_POISSON_LOG (no parameter),
-// GPT_OBS_NEG_BINOMIAL_2_LOG (theta = precision phi; mean exp(f)). All normalising constants are kept, as in
-// gp_rfft2_lpdf (fft2.stan:189-192).
-template <int FAM> __device__ __forceinline__ ObsTerm obs_term(double y, double f, double th, const double* k) {
-    ObsTerm t;
-    if (FAM == GPT_OBS_NORMAL) {
-        // k[0] = 1 / theta, k[1] = log(theta)
-        const double r = (y - f) * k[0];
-        t.lp = -0.5 * r * r - k[1] - HALF_LOG_2PI;
-        t.df = r * k[0];
-        t.dth = (r * r - 1.0) * k[0];
-    } else if (FAM == GPT_OBS_POISSON_LOG) {
-        const double mu = exp(f);
-        t.lp = y * f - mu - lgamma(y + 1.0);
-        t.df = y - mu;
-        t.dth = 0.0;
-    } else {
-        // k[0] = log(phi), k[1] = lgamma(phi), k[2] = digamma(phi)
-        const double lse = log_sum_exp2(f, k[0]); // log(mu + phi)
-        const double npf = y + th;
-        t.lp = lgamma(npf) - lgamma(y + 1.0) - k[1] + y * (f - lse) + th * (k[0] - lse);
-        t.df = y - npf * exp(f - lse);
-        t.dth = digamma_pos(npf) - k[2] + k[0] - lse + 1.0 - npf * exp(-lse);
-    }
-    return t;
-}
 
 template <int FAM> __global__ void __launch_bounds__(256) obs_kernel(ObsArgs a, double* partials) {
     const int64_t b = blockIdx.y;
@@ -72,15 +21,8 @@ template <int FAM> __global__ void __launch_bounds__(256) obs_kernel(ObsArgs a, 
     const double* y = a.obs + b * a.obs_bs;
     double* fb = a.fbar + b * tot;
     const double th = a.theta ? a.theta[b] : 0.0;
-    double k[3] = {0.0, 0.0, 0.0};
-    if (FAM == GPT_OBS_NORMAL) {
-        k[0] = 1.0 / th;
-        k[1] = log(th);
-    } else if (FAM == GPT_OBS_NEG_BINOMIAL_2_LOG) {
-        k[0] = log(th);
-        k[1] = lgamma(th);
-        k[2] = digamma_pos(th);
-    }
+    double k[3];
+    obs_consts(FAM, th, k);
     double s[4] = {0.0, 0.0, 0.0, 0.0}; // log density, d/dtheta, sum of d/df, observed points
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < tot; w += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(w / a.W), j = (int)(w - (int64_t)i * a.W);

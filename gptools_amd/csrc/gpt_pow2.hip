@@ -150,6 +150,32 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
     return hipErrorInvalidValue;
 }
 
+// Fused rows of the non-centred model density (row_obs_kernel): between pass 1 of OP_GP_INV_RFFT2 and pass 1 of
+// OP_INV_VJP on the same workspace. `a` carries the arguments of the inverse transform (loc, cov, min_eig, plans);
+// `partials` are those of its column pass (summed here into min_eig), o.partials the observation model's.
+bool gpt_pow2_obs_supported(int H, int W) { return gpt_pow2_supported(H, W) && W <= 8192; }
+int gpt_pow2_obs_blocks(int H, int W) {
+    int nb = 0;
+    (void)by_size(W, [&](auto l) {
+        nb = decltype(l)::row_obs_blocks(H);
+        return hipSuccess;
+    });
+    return nb;
+}
+hipError_t gpt_pow2_obs_rows(const LatArgs& a, cplx* ws, double* partials, int col_cus, const ObsRowArgs& o,
+                             hipStream_t st) {
+    if (!gpt_pow2_obs_supported(a.H, a.W)) return hipErrorInvalidValue;
+    const int wstride = a.W / 2 + GPT_WS_PAD;
+    const int R = a.tw_sub ? gpt_pow2_sub_radix(OP_GP_INV_RFFT2, a.H, a.W) : 0;
+    if (R != 0 && R != 2) return hipErrorInvalidValue;
+    if (R != (a.tw_sub ? gpt_pow2_sub_radix(OP_INV_VJP, a.H, a.W) : 0)) return hipErrorInvalidValue;
+    const int nblk = R ? sub_col_blocks(R, a.H, a.W, col_cus) : whole_col_blocks(a.H, a.W, col_cus);
+    FinArgs fin = {partials, nblk, 0.0, nullptr, a.min_eig};
+    double* edge = reinterpret_cast<double*>(ws + (size_t)a.batch * ws_spec_elems(a.H, a.W));
+    const double alpha = 1.0 / ((double)a.H * (double)a.W);
+    return by_size(a.W, [&](auto l) { return decltype(l)::row_obs(a, alpha, ws, wstride, fin, a.cov ? edge : nullptr, o, R == 2, st); });
+}
+
 // Columns a column-pass workgroup takes at once for lines of length H: slab widths must be multiples of it.
 int gpt_pow2_col_tile(int H) {
     int tc = 0;

@@ -25,6 +25,7 @@
 #pragma once
 #include "gpt_common.h"
 #include "gpt_host.h"
+#include "gpt_obs_dev.h"
 
 #ifndef GPT_TRACE
 #define GPT_TRACE 0
@@ -575,6 +576,158 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
     }
 }
 
+// pass C of gp_inv_rfft2, an observation model on the field, and pass A of the transform's reverse mode in one
+// kernel (gpt_gp_inv_rfft2_obs_lpdf_vjp): the workspace rows of this line come in as the spectrum of f and go out,
+// in place, as the spectrum of d lp / d f. f and d/df exist only in LDS unless the caller asks for copies.
+// `lds` (W doubles per line) is the transforms' exchange space and, in between, the thread-private staging of the
+// rows' points for a rolled loop over them.
+template <int W, bool SUB2 = false>
+__global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_obs_kernel(LatArgs a, double alpha, cplx* ws, int wstride,
+                                                                      FinArgs fin, double* __restrict__ edge,
+                                                                      ObsRowArgs o) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = Geo<W>::T, LINES = Geo<W>::ROW_LINES;
+    const int line = threadIdx.x / T, t = threadIdx.x - line * T;
+    double* lds = reinterpret_cast<double*>(smem) + (size_t)line * W;
+    const int64_t b = blockIdx.y;
+    const int H = a.H;
+    const int r = blockIdx.x * LINES + line;
+    const bool active = r < H / 2;
+    const int rr = active ? r : 0;
+    const int ra = SUB2 ? rr : 2 * rr, rb = SUB2 ? rr + H / 2 : 2 * rr + 1;
+    cplx* s0 = ws + ((int64_t)b * H + ra) * wstride;
+    cplx* s1 = ws + ((int64_t)b * H + rb) * wstride;
+    cplx wr = make_double2(1.0, 0.0);
+    if (SUB2) wr = a.ph.tw[rr];
+    cplx wpre[tw_npre<W>()];
+    tw_load<W>(wpre, a.pw.tw, t);
+    cplx v[E];
+    { // as row_inv_kernel
+        const cplx wc = cconj(wr);
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int j = t + T * m;
+            const int q = W - j;
+            const int col = m < E / 2 ? j : (q == W / 2 ? 0 : q);
+            cplx A = s0[col], B = s1[col];
+            if (SUB2) {
+                const cplx u = cmul(B, wc);
+                B = csub(A, u);
+                A = cadd(A, u);
+            }
+            if (m < E / 2) {
+                if (j == 0) v[m] = make_double2(A.x, B.x);
+                else v[m] = make_double2(A.x - B.y, A.y + B.x);
+            } else {
+                if (q == W / 2) v[m] = make_double2(A.y, B.y);
+                else v[m] = make_double2(A.x + B.y, -A.y + B.x);
+            }
+        }
+    }
+    fft_regs<W, true>(v, t, lds, wpre);
+    __syncthreads();
+    if (fin.partials && blockIdx.x == 0) {
+        finalize_block(fin, b, reinterpret_cast<double*>(smem));
+        __syncthreads();
+    }
+    // Half a row at a time: f = alpha * value + loc and the data go to the thread's own LDS positions, obs_points
+    // (a real call: one copy of the densities' code) turns them into d lp / d f, which comes back into the registers.
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+        const double th = o.theta ? o.theta[b] : 0.0;
+        double k[3];
+        obs_consts(o.family, th, k);
+        const double* ob = o.obs + b * o.obs_bs;
+        constexpr int EH = E / 2;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int half = ph >> 1, m0 = (ph & 1) * EH;
+            const int row = half ? rb : ra;
+            const double* l = a.loc ? a.loc + b * a.loc_bs + (int64_t)row * W : nullptr;
+            // the data of these points (NaN = nothing observed there) and loc: EH loads each in flight together
+            double yv[EH], lv[EH];
+            const bool in_rows = active && row < o.oh;
+#pragma unroll
+            for (int m = 0; m < EH; ++m) {
+                const int j = t + T * (m0 + m);
+                yv[m] = (in_rows && j < o.ow) ? ob[(int64_t)row * o.ow + j] : __builtin_nan("");
+                lv[m] = l ? l[j] : 0.0;
+            }
+#pragma unroll
+            for (int m = 0; m < EH; ++m) {
+                lds[t + T * m] = fma(alpha, half ? v[m0 + m].y : v[m0 + m].x, lv[m]);
+                lds[W / 2 + t + T * m] = yv[m];
+            }
+            double* fo = (o.f_out && active) ? o.f_out + (b * H + row) * (int64_t)W + T * m0 : nullptr;
+            double* go = (o.fbar_out && active) ? o.fbar_out + (b * H + row) * (int64_t)W + T * m0 : nullptr;
+            const ObsSums ps = obs_points(lds + t, lds + W / 2 + t, EH, T, o.family, th, k[0], k[1], k[2], fo ? fo + t : nullptr,
+                                          go ? go + t : nullptr);
+            s[0] += ps.lp;
+            s[1] += ps.dth;
+            s[2] += ps.df;
+            s[3] += ps.n;
+#pragma unroll
+            for (int m = 0; m < EH; ++m) {
+                if (half) v[m0 + m].y = lds[t + T * m];
+                else v[m0 + m].x = lds[t + T * m];
+            }
+        }
+    }
+    block_reduce_store<4>(s, INFINITY, o.partials, b); // (synchronises: the staging is free again)
+    // as row_fwd_kernel
+    fft_regs<W, false>(v, t, lds, wpre);
+    cplx zc[E / 2];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m].x;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E / 2; ++m) {
+        const int j = t + T * m;
+        zc[m].x = lds[phys(j == 0 ? 0 : W - j)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m].y;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < E / 2; ++m) {
+        const int j = t + T * m;
+        zc[m].y = lds[phys(j == 0 ? 0 : W - j)];
+    }
+    if (!active) return;
+    if (edge && a.cov && t == 0) {
+        const double* cv = a.cov + b * a.cov_bs;
+        const int wf = W / 2 + 1;
+        double* e = edge + b * 4 * (int64_t)H;
+        e[ra] = cv[(int64_t)ra * wf];
+        e[rb] = cv[(int64_t)rb * wf];
+        e[H + ra] = cv[(int64_t)ra * wf + W / 2];
+        e[H + rb] = cv[(int64_t)rb * wf + W / 2];
+    }
+#pragma unroll
+    for (int m = 0; m < E / 2; ++m) {
+        const int j = t + T * m;
+        const cplx z = v[m];
+        cplx za, zb;
+        if (j == 0) {
+            const cplx zn = v[E / 2];
+            za = make_double2(z.x, zn.x);
+            zb = make_double2(z.y, zn.y);
+        } else {
+            za = make_double2(0.5 * (z.x + zc[m].x), 0.5 * (z.y - zc[m].y));
+            zb = make_double2(0.5 * (z.y + zc[m].y), -0.5 * (z.x - zc[m].x));
+        }
+        if (SUB2) {
+            s0[j] = cadd(za, zb);
+            s1[j] = cmul(csub(za, zb), wr);
+        } else {
+            s0[j] = za;
+            s1[j] = zb;
+        }
+    }
+}
+
 // pass B --------------------------------------------------------------------------------------------
 // Persistent: a workgroup walks over several column tiles (TC adjacent packed columns each).
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 labels the XCD),
@@ -773,6 +926,11 @@ template <int N> struct Launch {
                               const FinArgs& fin, const double* edge, bool sub2, hipStream_t st);
     static hipError_t col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg, double* edge,
                           int edge_flags, hipStream_t st);
+    // inverse rows -> observation model -> forward rows, in place (rows of up to 8192 points); its grid is
+    // row_obs_blocks(H) workgroups per lattice = partials per lattice in ObsRowArgs
+    static hipError_t row_obs(const LatArgs& a, double alpha, cplx* ws, int wstride, const FinArgs& fin, double* edge,
+                              const ObsRowArgs& o, bool sub2, hipStream_t st);
+    static int row_obs_blocks(int H) { return (H / 2 + Geo<N>::ROW_LINES - 1) / Geo<N>::ROW_LINES; }
     // grid of the persistent column kernel = number of per-lattice partials, one workgroup per CU it may use
     static int col_tile() { return Geo<N>::TC; }
     static int col_blocks(int W, int cus) {

@@ -57,6 +57,31 @@ hipError_t Launch<GPT_N>::row_inv(const LatArgs& a, double alpha, int add_loc, c
 }
 
 #if GPT_N <= 8192
+template <>
+hipError_t Launch<GPT_N>::row_obs(const LatArgs& a, double alpha, cplx* ws, int wstride, const FinArgs& fin, double* edge,
+                                  const ObsRowArgs& o, bool sub2, hipStream_t st) {
+    constexpr int W = GPT_N;
+    const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(double);
+    hipError_t e = sub2 ? raise_lds(row_obs_kernel<W, true>, lds) : raise_lds(row_obs_kernel<W, false>, lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)row_obs_blocks(a.H), (unsigned)a.batch);
+    if (sub2)
+        hipLaunchKernelGGL((row_obs_kernel<W, true>), grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, alpha, ws, wstride, fin,
+                           edge, o);
+    else
+        hipLaunchKernelGGL((row_obs_kernel<W, false>), grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, alpha, ws, wstride, fin,
+                           edge, o);
+    return hipGetLastError();
+}
+#else
+template <>
+hipError_t Launch<GPT_N>::row_obs(const LatArgs&, double, cplx*, int, const FinArgs&, double*, const ObsRowArgs&, bool,
+                                  hipStream_t) {
+    return hipErrorInvalidValue;
+}
+#endif
+
+#if GPT_N <= 8192
 template <int OP>
 static hipError_t col_t(const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg, double* edge,
                         int edge_flags, hipStream_t st) {

@@ -434,7 +434,7 @@ def gp_rfft2_vjp(y, loc, cov_rfft2, zbar):
 OBS_FAMILIES = {"normal": 0, "poisson_log": 1, "neg_binomial_2_log": 2}
 
 
-def _obs_lpdf_vjp(family, z, loc, cov, obs, theta, prior, dim1, check, need_cov_grad):
+def _obs_lpdf_vjp(family, z, loc, cov, obs, theta, prior, dim1, check, need_cov_grad, need_f=True):
     g = _prep(z, loc, cov, dim1)
     core = 1 if dim1 else 2
     obs = _dev(obs, g["main"])
@@ -449,9 +449,9 @@ def _obs_lpdf_vjp(family, z, loc, cov, obs, theta, prior, dim1, check, need_cov_
         th = _dev(theta, g["main"]).expand(g["bshape"]).contiguous()
     lp, mn, gls = _new(g), _new(g), _new(g)
     gth = _new(g) if th is not None else None
-    f = torch.empty_like(g["main"])
+    f = torch.empty_like(g["main"]) if need_f else None
     gz = torch.empty_like(g["main"])
-    gl = torch.empty_like(g["main"])
+    gl = torch.empty_like(g["main"]) if need_f else None
     gc = _new(g, *((g["Wf"],) if dim1 else (g["H"], g["Wf"]))) if need_cov_grad else None
     get_context(lp.device).call("gpt_gp_inv_rfft2_obs_lpdf_vjp", fam, _p(g["main"]), g["m_bs"], _p(g["loc"]), g["l_bs"],
                                 _p(g["cov"]), g["c_bs"], _p(obs), o_bs, oh, ow, _p(th), int(bool(prior)), g["H"], g["W"],
@@ -460,19 +460,23 @@ def _obs_lpdf_vjp(family, z, loc, cov, obs, theta, prior, dim1, check, need_cov_
     return dict(lp=lp, f=f, grad_z=gz, grad_loc=gl, grad_loc_sum=gls, grad_cov=gc, grad_theta=gth)
 
 
-def gp_inv_rfft2_obs_lpdf_vjp(family, z, loc, cov_rfft2, obs, theta=None, prior=True, check=True, need_cov_grad=True):
+def gp_inv_rfft2_obs_lpdf_vjp(family, z, loc, cov_rfft2, obs, theta=None, prior=True, check=True, need_cov_grad=True,
+                              need_f=True):
     """Log density and gradients of a non-centred docs model on the device: ``f = gp_inv_rfft2(z, loc, cov)``
     (fft2.stan:126-130), ``lp = sum family_lpdf(obs | f, theta) [+ std_normal_lpdf(z)]`` over the ``obs`` corner of the
     (padded) lattice, NaN / negative counts masked (docs/trees/trees.stan:31-49). ``family``: ``"normal"`` (theta =
     standard deviation), ``"poisson_log"``, ``"neg_binomial_2_log"`` (theta = precision; trees.stan passes 1/kappa).
-    Returns a dict: ``lp, f, grad_z, grad_loc`` (= d lp / d f), ``grad_loc_sum, grad_cov, grad_theta``."""
-    return _obs_lpdf_vjp(family, z, loc, cov_rfft2, obs, theta, prior, False, check, need_cov_grad)
+    Returns a dict: ``lp, f, grad_z, grad_loc`` (= d lp / d f), ``grad_loc_sum, grad_cov, grad_theta``. With
+    ``need_f=False`` the field and its gradient are not returned (a sampler with a scalar ``loc`` needs neither) and,
+    on power-of-two lattices, never reach HBM."""
+    return _obs_lpdf_vjp(family, z, loc, cov_rfft2, obs, theta, prior, False, check, need_cov_grad, need_f)
 
 
-def gp_inv_rfft_obs_lpdf_vjp(family, z, loc, cov_rfft, obs, theta=None, prior=True, check=True, need_cov_grad=True):
+def gp_inv_rfft_obs_lpdf_vjp(family, z, loc, cov_rfft, obs, theta=None, prior=True, check=True, need_cov_grad=True,
+                             need_f=True):
     """1-D sibling: docs/padding/padded.stan:29-34 (``obs = y[:observe_first]``),
     docs/poisson_regression/poisson_regression_fourier_non_centered.stan:20-26."""
-    return _obs_lpdf_vjp(family, z, loc, cov_rfft, obs, theta, prior, True, check, need_cov_grad)
+    return _obs_lpdf_vjp(family, z, loc, cov_rfft, obs, theta, prior, True, check, need_cov_grad, need_f)
 
 
 # ---- spectral kernels ------------------------------------------------------------------------------
