@@ -278,7 +278,7 @@ ElemArgs elem_args(int64_t H, int64_t W, int64_t batch, int dim1) {
 int run_obs_fused(gpt_ctx* c, int family, const double* z, int64_t z_bs, const double* loc, int64_t loc_bs,
                   const double* cov, int64_t cov_bs, const double* obs, int64_t obs_bs, int oh, int ow,
                   const double* theta, int H, int W, int64_t batch, double* f_out, double* fbar_out, double* grad_z,
-                  double* grad_cov, double* min_eig, double* sums) {
+                  double* grad_cov, double* min_eig, double* sums, double* psum) {
     int rc;
     LatArgs a = base_args(H, W, batch, 0);
     if ((rc = make_plan(c, W, a.pw)) != GPT_OK) return rc;
@@ -330,6 +330,8 @@ int run_obs_fused(gpt_ctx* c, int family, const double* z, int64_t z_bs, const d
         sv.cov = si.cov; sv.cov_bs = cov_bs;
         sv.out = grad_z + b0 * hw;
         sv.out_cov = grad_cov ? grad_cov + b0 * hwf : c->sink;
+        sv.zprior = psum ? 1 : 0;
+        sv.out_lpdf = psum ? psum + b0 : nullptr;
         HIP_TRY(c, gpt_pow2_pass(1, OP_INV_VJP, sv, c->ws, c->partials, c->total_cus, c->stream));
     }
     return GPT_OK;
@@ -686,9 +688,11 @@ int gpt_gp_rfft2_lpdf_vjp(gpt_ctx* c, const double* y, int64_t y_bs, const doubl
     return run_lattice(c, grad_cov ? OP_LPDF_VJP : OP_LPDF_VJP_NOCOV, a);
 }
 
-int gpt_gp_inv_rfft2_vjp(gpt_ctx* c, const double* z, int64_t z_bs, const double* cov, int64_t cov_bs,
+// prior_lp != null: the white-noise prior of the non-centred models rides along (zbar -= z, prior_lp[b] =
+// std_normal_lpdf(z[b])): the column pass reads z and writes zbar anyway
+static int inv_rfft2_vjp(gpt_ctx* c, const double* z, int64_t z_bs, const double* cov, int64_t cov_bs,
                          const double* fbar, int64_t fbar_bs, int64_t H, int64_t W, int64_t batch, int dim1,
-                         double* zbar, double* covbar) {
+                         double* zbar, double* covbar, double* prior_lp) {
     int rc = check_shape(c, H, W, batch, dim1);
     if (rc) return rc;
     LatArgs a = base_args(H, W, batch, dim1);
@@ -697,11 +701,19 @@ int gpt_gp_inv_rfft2_vjp(gpt_ctx* c, const double* z, int64_t z_bs, const double
     a.aux = fbar; a.aux_bs = fbar_bs;
     a.out = zbar;
     a.out_cov = covbar;
+    a.zprior = prior_lp ? 1 : 0;
+    a.out_lpdf = prior_lp;
     if (!covbar) {
         if ((rc = ensure(c, c->sink, c->sink_bytes, sizeof(double) * (size_t)batch * H * (W / 2 + 1)))) return rc;
         a.out_cov = c->sink;
     }
     return run_lattice(c, OP_INV_VJP, a);
+}
+
+int gpt_gp_inv_rfft2_vjp(gpt_ctx* c, const double* z, int64_t z_bs, const double* cov, int64_t cov_bs,
+                         const double* fbar, int64_t fbar_bs, int64_t H, int64_t W, int64_t batch, int dim1,
+                         double* zbar, double* covbar) {
+    return inv_rfft2_vjp(c, z, z_bs, cov, cov_bs, fbar, fbar_bs, H, W, batch, dim1, zbar, covbar, nullptr);
 }
 
 int gpt_gp_rfft2_vjp(gpt_ctx* c, const double* y, int64_t y_bs, const double* loc, int64_t loc_bs,
@@ -833,17 +845,9 @@ int gpt_gp_inv_rfft2_obs_lpdf_vjp(gpt_ctx* c, int family, const double* z, int64
         double* sums = c->oscr;
         double* psum = sums + 4 * batch;
         if ((rc = run_obs_fused(c, family, z, z_bs, loc, loc_bs, cov, cov_bs, obs, obs_bs, (int)oh, (int)ow, theta, (int)H,
-                                (int)W, batch, f_out, grad_loc, grad_z, grad_cov, min_eig, sums)) != GPT_OK)
+                                (int)W, batch, f_out, grad_loc, grad_z, grad_cov, min_eig, sums, prior ? psum : nullptr)) !=
+            GPT_OK)
             return rc;
-        for (int64_t b0 = 0; prior && b0 < batch; b0 += 32768) {
-            const int64_t nb = batch - b0 < 32768 ? batch - b0 : 32768;
-            if ((rc = ensure(c, c->partials, c->partials_bytes, sizeof(double) * GPT_PART * (size_t)nblk * (size_t)nb)) !=
-                GPT_OK)
-                return rc;
-            HIP_TRY(c, gpt_launch_prior(z + b0 * z_bs, z_bs, grad_z + b0 * hw, (int)H, (int)W, nb, c->partials, c->stream));
-            HIP_TRY(c, gpt_launch_finalize(c->partials, nblk, nb, 1, -0.5 * (double)hw * std::log(2.0 * M_PI), psum + b0,
-                                           nullptr, c->stream));
-        }
         HIP_TRY(c, gpt_launch_obs_combine(sums, prior ? psum : nullptr, batch, lp, grad_theta, grad_loc_sum, nullptr,
                                           c->stream));
         return GPT_OK;
@@ -881,18 +885,9 @@ int gpt_gp_inv_rfft2_obs_lpdf_vjp(gpt_ctx* c, int family, const double* z, int64
         o.fbar = fbar;
         HIP_TRY(c, gpt_launch_obs(o, c->partials, c->stream));
         HIP_TRY(c, gpt_launch_finalize(c->partials, nblk, nb, 4, 0.0, sums, nullptr, c->stream));
-        if ((rc = gpt_gp_inv_rfft2_vjp(c, zb, z_bs, cb, cov_bs, fbar, hw, H, W, nb, dim1, grad_z + b0 * hw,
-                                       grad_cov ? grad_cov + b0 * hwf : nullptr)) != GPT_OK)
+        if ((rc = inv_rfft2_vjp(c, zb, z_bs, cb, cov_bs, fbar, hw, H, W, nb, dim1, grad_z + b0 * hw,
+                                grad_cov ? grad_cov + b0 * hwf : nullptr, prior ? psum : nullptr)) != GPT_OK)
             return rc;
-        if (prior) {
-            // the passes above may have regrown the partials
-            if ((rc = ensure(c, c->partials, c->partials_bytes, sizeof(double) * GPT_PART * (size_t)nblk * (size_t)nb)) !=
-                GPT_OK)
-                return rc;
-            HIP_TRY(c, gpt_launch_prior(zb, z_bs, grad_z + b0 * hw, (int)H, (int)W, nb, c->partials, c->stream));
-            HIP_TRY(c, gpt_launch_finalize(c->partials, nblk, nb, 1, -0.5 * (double)hw * std::log(2.0 * M_PI), psum, nullptr,
-                                           c->stream));
-        }
         HIP_TRY(c, gpt_launch_obs_combine(sums, prior ? psum : nullptr, nb, lp + b0, grad_theta ? grad_theta + b0 : nullptr,
                                           grad_loc_sum ? grad_loc_sum + b0 : nullptr, nullptr, c->stream));
     }

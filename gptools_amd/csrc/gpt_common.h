@@ -72,7 +72,8 @@ struct LatArgs {
     double* out;      // H x W real per lattice
     double* out_cov;  // H x Wf real per lattice (may be null)
     cplx* out_c;      // H x Wf complex per lattice (OP_RFFT2)
-    double* out_lpdf; // [batch]
+    double* out_lpdf; // [batch]; OP_INV_VJP with zprior: std_normal_lpdf(z)
+    int zprior;       // OP_INV_VJP: add the white-noise prior z ~ std_normal() (trees.stan:37): zbar -= z, its log density
     double* min_eig;  // [batch]: min over the whole H x Wf matrix of n*c/2 (may be null)
     LinePlan pw, ph;  // line plans for length W and length H
     // Column slab (one lattice split over several GPUs, gpt_slab_*): the column pass works on packed columns
@@ -415,8 +416,10 @@ __device__ __forceinline__ cplx ew_interior_ic(const LatArgs& a, const ZLayout& 
         const double s = sqrt(0.5 * n * c);
         const double pr = P.x[iz + L.re_col(j)], pi = P.x[iz + L.im_col(j)];
         const double k2 = 2.0 / n;
-        P.out[iz + L.re_col(j)] = k2 * s * F.x;
-        P.out[iz + L.im_col(j)] = k2 * s * F.y;
+        const double pz = a.zprior ? 1.0 : 0.0;
+        P.out[iz + L.re_col(j)] = fma(-pz, pr, k2 * s * F.x);
+        P.out[iz + L.im_col(j)] = fma(-pz, pi, k2 * s * F.y);
+        acc.sum -= pz * 0.5 * fma(pr, pr, pi * pi);
         const double sbar = k2 * fma(pr, F.x, pi * F.y);
         P.out_cov[ic] = sbar * s / (2.0 * c);
     } else if (OP == OP_FWD_VJP) {
@@ -534,16 +537,20 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
         }
     } else if (OP == OP_INV_VJP) {
         const double k1 = 1.0 / n;
+        const double pz = a.zprior ? 1.0 : 0.0;
         if (real_pt) {
             const double s = sqrt(n * c);
-            P.out[zr] = k1 * s * FA.x;
-            const double sbar = k1 * P.x[zr] * FA.x;
+            const double pr = P.x[zr];
+            P.out[zr] = fma(-pz, pr, k1 * s * FA.x);
+            acc.sum -= pz * 0.5 * pr * pr;
+            const double sbar = k1 * pr * FA.x;
             P.out_cov[ck] = sbar * s / (2.0 * c);
         } else {
             const double s = sqrt(0.5 * n * c), sm = sqrt(0.5 * n * cm);
             const double pr = P.x[zr], pi = P.x[zi];
-            P.out[zr] = k1 * (s + sm) * FA.x;
-            P.out[zi] = k1 * (s + sm) * FA.y;
+            P.out[zr] = fma(-pz, pr, k1 * (s + sm) * FA.x);
+            P.out[zi] = fma(-pz, pi, k1 * (s + sm) * FA.y);
+            acc.sum -= pz * 0.5 * fma(pr, pr, pi * pi);
             const double sbar = k1 * fma(pr, FA.x, pi * FA.y);
             P.out_cov[ck] = sbar * s / (2.0 * c);
             P.out_cov[cm_] = sbar * sm / (2.0 * cm);

@@ -270,7 +270,7 @@ hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partia
     }
     if (e != hipSuccess) return e;
     if (op != OP_RFFT2 && op != OP_INV_RFFT2) {
-        const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op));
+        const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op) || op == OP_INV_VJP); // (OP_INV_VJP: the z prior)
         e = gpt_launch_finalize(partials, nblk, a.batch, 1, -0.5 * n * 1.8378770664093454836,
                                 lp ? a.out_lpdf : nullptr, a.min_eig, st);
         if (e != hipSuccess) return e;

@@ -106,8 +106,5 @@ struct ObsArgs {
 // partials: batch * gpt_obs_blocks(H, W) * GPT_PART doubles; slots 0..3 = log density, d/dtheta, sum of d/df, points
 int gpt_obs_blocks(int H, int W);
 hipError_t gpt_launch_obs(const ObsArgs& a, double* partials, hipStream_t st);
-// zbar -= z; slot 0 = -sum z^2 / 2
-hipError_t gpt_launch_prior(const double* z, int64_t z_bs, double* zbar, int H, int W, int64_t batch, double* partials,
-                            hipStream_t st);
 hipError_t gpt_launch_obs_combine(const double* sums, const double* psum, int64_t batch, double* lp, double* grad_theta,
                                   double* grad_loc_sum, double* nobs, hipStream_t st);

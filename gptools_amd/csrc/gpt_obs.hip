@@ -45,21 +45,6 @@ template <int FAM> __global__ void __launch_bounds__(256) obs_kernel(ObsArgs a, 
     block_reduce_store<4>(s, INFINITY, partials, b);
 }
 
-// z ~ std_normal() (trees.stan:37): zbar -= z, partial sums of -z^2 / 2
-__global__ void __launch_bounds__(256) prior_kernel(const double* __restrict__ z, int64_t z_bs, double* __restrict__ zbar,
-                                                    int64_t tot, double* partials) {
-    const int64_t b = blockIdx.y;
-    const double* zb = z + b * z_bs;
-    double* o = zbar + b * tot;
-    double s[1] = {0.0};
-    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < tot; w += (int64_t)gridDim.x * blockDim.x) {
-        const double v = zb[w];
-        o[w] -= v;
-        s[0] -= 0.5 * v * v;
-    }
-    block_reduce_store<1>(s, INFINITY, partials, b);
-}
-
 __global__ void obs_combine_kernel(const double* sums, const double* psum, int64_t batch, double* lp, double* grad_theta,
                                    double* grad_loc_sum, double* nobs) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,15 +76,6 @@ hipError_t gpt_launch_obs(const ObsArgs& a, double* partials, hipStream_t st) {
         break;
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
-}
-
-hipError_t gpt_launch_prior(const double* z, int64_t z_bs, double* zbar, int H, int W, int64_t batch, double* partials,
-                            hipStream_t st) {
-    if (batch <= 0) return hipSuccess;
-    if (batch > 65535) return hipErrorInvalidValue;
-    dim3 grid((unsigned)gpt_obs_blocks(H, W), (unsigned)batch), block(256);
-    hipLaunchKernelGGL(prior_kernel, grid, block, 0, st, z, z_bs, zbar, (int64_t)H * W, partials);
     return hipGetLastError();
 }
 

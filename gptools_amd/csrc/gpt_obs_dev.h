@@ -7,16 +7,18 @@ namespace {
 
 constexpr double HALF_LOG_2PI = 0.91893853320467274178;
 
-// lgamma(x) and digamma(x), x > 0: recurrence up to x >= 10, then Stirling's series (next terms < 4e-17). One
+// lgamma(x) and digamma(x), x > 0: recurrence (as a running product) up to x >= 10, then Stirling's series (next terms < 4e-17). One
 // logarithm is shared; far cheaper than the general-purpose lgamma, which matters when every point of a lattice
 // evaluates it (negative-binomial counts).
 __device__ __forceinline__ void lgamma_digamma_pos(double x, double& lg, double& dg) {
-    double r = 0.0, p = 1.0;
+    // p = x (x + 1) ... (x + k - 1) and its derivative dp: sum of 1 / (x + i) = dp / p, one division for the lot
+    double p = 1.0, dp = 0.0;
     while (x < 10.0) {
-        r -= 1.0 / x;
+        dp = fma(dp, x, p);
         p *= x;
         x += 1.0;
     }
+    const double r = -dp / p;
     const double lx = log(x), i = 1.0 / x, i2 = i * i;
     const double ser =
         i2 * (1.0 / 12 - i2 * (1.0 / 120 - i2 * (1.0 / 252 - i2 * (1.0 / 240 - i2 * (1.0 / 132 - i2 * (691.0 / 32760 - i2 / 12))))));
@@ -24,6 +26,32 @@ __device__ __forceinline__ void lgamma_digamma_pos(double x, double& lg, double&
     const double st =
         i * (1.0 / 12 - i2 * (1.0 / 360 - i2 * (1.0 / 1260 - i2 * (1.0 / 1680 - i2 * (1.0 / 1188 - i2 * (691.0 / 360360 - i2 / 156))))));
     lg = (x - 0.5) * lx - x + HALF_LOG_2PI + st - (p == 1.0 ? 0.0 : log(p));
+}
+// log(k!) for k < 64: counts are small integers nearly everywhere (trees.stan: trees per quadrat)
+__device__ const double GPT_LOG_FACT[64] = {
+    0.0, 0.0, 0.6931471805599453, 1.791759469228055,
+    3.1780538303479458, 4.787491742782046, 6.579251212010101, 8.525161361065415,
+    10.60460290274525, 12.801827480081469, 15.104412573075516, 17.502307845873887,
+    19.987214495661885, 22.552163853123425, 25.19122118273868, 27.89927138384089,
+    30.671860106080672, 33.50507345013689, 36.39544520803305, 39.339884187199495,
+    42.335616460753485, 45.38013889847691, 48.47118135183523, 51.60667556776438,
+    54.78472939811232, 58.00360522298052, 61.261701761002, 64.55753862700634,
+    67.88974313718154, 71.25703896716801, 74.65823634883016, 78.0922235533153,
+    81.55795945611504, 85.05446701758152, 88.58082754219768, 92.1361756036871,
+    95.7196945421432, 99.33061245478743, 102.96819861451381, 106.63176026064346,
+    110.32063971475739, 114.0342117814617, 117.77188139974507, 121.53308151543864,
+    125.3172711493569, 129.12393363912722, 132.95257503561632, 136.80272263732635,
+    140.67392364823425, 144.5657439463449, 148.47776695177302, 152.40959258449735,
+    156.3608363030788, 160.3311282166309, 164.32011226319517, 168.32744544842765,
+    172.3527971391628, 176.39584840699735, 180.45629141754378, 184.53382886144948,
+    188.6281734236716, 192.7390472878449, 196.86618167289, 201.00931639928152,
+};
+// lgamma(y + 1) for a count y >= 0
+__device__ __forceinline__ double log_factorial(double y) {
+    if (y < 64.0 && y == floor(y)) return GPT_LOG_FACT[(int)y];
+    double lg, dg;
+    lgamma_digamma_pos(y + 1.0, lg, dg);
+    return lg;
 }
 __device__ __forceinline__ double digamma_pos(double x) {
     double lg, dg;
@@ -59,7 +87,7 @@ template <int FAM> __device__ __forceinline__ ObsTerm obs_term(double y, double 
         t.dth = (r * r - 1.0) * k[0];
     } else if (FAM == GPT_OBS_POISSON_LOG) {
         const double mu = exp(f);
-        t.lp = y * f - mu - lgamma_pos(y + 1.0);
+        t.lp = y * f - mu - log_factorial(y);
         t.df = y - mu;
         t.dth = 0.0;
     } else {
@@ -68,7 +96,7 @@ template <int FAM> __device__ __forceinline__ ObsTerm obs_term(double y, double 
         const double npf = y + th;
         double lg, dg;
         lgamma_digamma_pos(npf, lg, dg);
-        t.lp = lg - lgamma_pos(y + 1.0) - k[1] + y * (f - lse) + th * (k[0] - lse);
+        t.lp = lg - log_factorial(y) - k[1] + y * (f - lse) + th * (k[0] - lse);
         t.df = y - npf * exp(f - lse);
         t.dth = dg - k[2] + k[0] - lse + 1.0 - npf * exp(-lse);
     }

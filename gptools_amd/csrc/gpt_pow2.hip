@@ -98,7 +98,7 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
     if (op_is_kvjp(op) && !sub) return hipErrorInvalidValue; // only the sub-line kernel evaluates the spectrum
     const int nblk = sub ? sub_col_blocks(R, a.H, a.W, col_cus) : whole_col_blocks(a.H, a.W, col_cus);
     const bool reduces = (op != OP_RFFT2 && op != OP_INV_RFFT2);
-    const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op));
+    const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op) || op == OP_INV_VJP); // (OP_INV_VJP: the z prior, if asked)
     const double add = -0.5 * n * 1.8378770664093454836;
     // edge-column staging (speed only): cov by pass A when the op has one and reads cov; d/dcov through pass C
     // for the fused log-density gradient

@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         block_sum_min(s, m, red);
         if (threadIdx.x == 0) {
             const double lp = s - 0.5 * (double)H * (double)W * 1.8378770664093454836;
-            if ((OP == OP_LPDF || op_is_lpdf_vjp(OP)) && a.out_lpdf) a.out_lpdf[b] = lp;
+            if ((OP == OP_LPDF || op_is_lpdf_vjp(OP) || OP == OP_INV_VJP) && a.out_lpdf) a.out_lpdf[b] = lp;
             if (op_is_kvjp(OP) && a.ksums) {
                 a.ksums[4 * b] = lp;
                 a.ksums[4 * b + 1] = kk[0];
