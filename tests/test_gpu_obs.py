@@ -159,6 +159,32 @@ def test_obs_full_size_properties(fft, fused, monkeypatch):
     assert float((res["grad_z"] - zbar).abs().max()) <= 1e-12 * float(zbar.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(35, 60), (300, 210), (512, 256)])
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_obs_without_field_outputs(fft, shape, fused, monkeypatch):
+    """need_f=False: f and d lp / d f live in library scratch (or nowhere); everything else is unchanged. Five lattices
+    so that the library's chunking of its scratch is exercised as well."""
+    import torch
+
+    monkeypatch.setenv("GPT_OBS_FUSED", fused)
+    rng = np.random.default_rng(41)
+    H, W = shape
+    B = 5
+    z = rng.normal(size=(B, H, W))
+    loc = rng.normal(size=(H, W))
+    cov = o.gp_periodic_exp_quad_cov_rfft2(H, W, 0.7, np.array([2.0, 2.5]), np.array([H, W])) + 1e-3
+    obs, theta = _data("neg_binomial_2_log", rng, (H - 3, W - 5), (B,))
+    full = fft.gp_inv_rfft2_obs_lpdf_vjp("neg_binomial_2_log", z, loc, cov, obs, theta, True, need_cov_grad=False)
+    lean = fft.gp_inv_rfft2_obs_lpdf_vjp("neg_binomial_2_log", z, loc, cov, obs, theta, True, need_cov_grad=False,
+                                         need_f=False)
+    assert lean["f"] is None and lean["grad_loc"] is None and lean["grad_cov"] is None
+    for k in ("lp", "grad_z", "grad_loc_sum", "grad_theta"):
+        assert torch.equal(full[k], lean[k]), k
+    want = o.gp_inv_rfft2_obs_lpdf_vjp(o.OBS_NEG_BINOMIAL_2_LOG, z, loc, cov, obs, theta, True)
+    close(lean["lp"], want[0])
+    close(lean["grad_z"], want[2])
+
+
 def test_obs_rejects_bad_arguments(fft):
     z = np.zeros((4, 6))
     cov = np.ones((4, 4))
