@@ -165,7 +165,7 @@ __device__ __forceinline__ void col0_role(const LatArgs& a, const ZLayout& L, co
 template <int HS, int V, int THREADS, int OP>
 __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2))  // waves per SIMD the register budget must allow
     colsub_kernel(LatArgs a, int R, cplx* __restrict__ ws, int wstride, const cplx* __restrict__ tws,
-                  double* __restrict__ partials, int ntq, double* __restrict__ edge, int edge_flags) {
+                  double* __restrict__ partials, int ntq, double* __restrict__ edge, int edge_flags, int nact) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = GeoS<HS, V, THREADS>;
     constexpr int T = G::T, TC = G::TC, TP = G::TP;
@@ -206,8 +206,12 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
     const int ntiles = R * ntq;
     int first, step, count;
     {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        if ((nwg & 7) == 0 && (ntiles & 7) == 0) {
+        // the grid is as large as the lattice's partials; the first nact workgroups share the tiles (geometries
+        // that fit fewer workgroups on a CU), the others only write their neutral partial
+        const int nwg = nact, bid = blockIdx.x;
+        if (bid >= nact) {
+            first = step = count = 0;
+        } else if ((nwg & 7) == 0 && (ntiles & 7) == 0) {
             const int per = ntiles >> 3, i = bid >> 3;
             step = nwg >> 3;
             first = (bid & 7) * per + i;

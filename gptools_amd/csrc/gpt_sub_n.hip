@@ -79,17 +79,31 @@ hipError_t LaunchSub<GPT_N>::line_fft(bool inverse, cplx* data, int64_t nlines, 
 }
 
 #if GPT_N <= 4096
+// Ops whose elementwise stage reads or writes the real H x W layout of the whitened coefficients z: a workgroup's
+// pieces of those rows are TC doubles wide. Sub-lines of 2048 points give TC = 4 (32 bytes) with 256 threads; these
+// ops run 512-thread workgroups there (TC = 8, one workgroup per CU): +4..8 % on the non-centred model density,
+// while the ops that only touch the complex workspace and cov are faster with two small workgroups per CU.
+constexpr bool op_z_layout(int op) {
+    return op == OP_GP_RFFT2 || op == OP_GP_INV_RFFT2 || op == OP_INV_VJP || op == OP_FWD_VJP;
+}
 template <int OP>
 static hipError_t colsub_t(const LatArgs& a, int R, cplx* ws, int wstride, const cplx* tws, double* partials, int nwg,
                            double* edge, int edge_flags, hipStream_t st) {
     constexpr int HS = GPT_N;
-    const size_t lds = GS::lds_bytes();
-    hipError_t e = raise_lds_sub(colsub_kernel<HS, SUB_V, SUB_THREADS, OP>, lds);
+    constexpr int THREADS = (GPT_N == 2048 && op_z_layout(OP)) ? 512 : SUB_THREADS;
+    using G = GeoS<HS, SUB_V, THREADS>;
+    const size_t lds = G::lds_bytes();
+    hipError_t e = raise_lds_sub(colsub_kernel<HS, SUB_V, THREADS, OP>, lds);
     if (e != hipSuccess) return e;
-    const int ntq = (a.ncols > 0 ? a.ncols : a.W / 2) / GS::TC;
-    dim3 grid((unsigned)nwg, (unsigned)a.batch);
-    hipLaunchKernelGGL((colsub_kernel<HS, SUB_V, SUB_THREADS, OP>), grid, dim3(SUB_THREADS), lds, st, a, R, ws, wstride,
-                       tws, partials, ntq, edge, edge_flags);
+    const int ncols = a.ncols > 0 ? a.ncols : a.W / 2;
+    if (ncols % G::TC != 0) return hipErrorInvalidValue;
+    const int ntq = ncols / G::TC;
+    dim3 grid((unsigned)nwg, (unsigned)a.batch); // (nwg is the number of partials: the same for every geometry)
+    int nact = nwg;
+    if (THREADS != SUB_THREADS && SUB_WGS_PER_CU == 2 && nwg >= 16) nact = (nwg / 2) & ~7; // one workgroup per CU
+    if (nact < R / 2 + 1) nact = nwg;
+    hipLaunchKernelGGL((colsub_kernel<HS, SUB_V, THREADS, OP>), grid, dim3(THREADS), lds, st, a, R, ws, wstride, tws,
+                       partials, ntq, edge, edge_flags, nact);
     return hipGetLastError();
 }
 

@@ -21,7 +21,7 @@ def main():
     cov = fft.gp_periodic_matern_cov_rfft2(1.5, H, W, 0.8, [8.0, 12.0], [H, W]) + 1e-3
     loc = torch.full((H, W), 0.5, dtype=torch.float64, device=dev)
     need_f = os.environ.get("OBS_NEED_F", "1") != "0"
-    for family in ("neg_binomial_2_log", "poisson_log", "normal"):
+    for family in os.environ.get("OBS_FAMILIES", "neg_binomial_2_log,poisson_log,normal").split(","):
         for B in (1, 4):
             z = torch.randn(B, H, W, dtype=torch.float64, device=dev, generator=g)
             obs = torch.poisson(torch.full((oh, ow), 2.0, dtype=torch.float64, device=dev), generator=g)
