@@ -1063,6 +1063,45 @@ int gpt_gp_inv_rfft2_host(gpt_ctx* c, int layout, const double* z, const double*
     return s.finish(dm);
 }
 
+int gpt_gp_inv_rfft2_obs_lpdf_host(gpt_ctx* c, int layout, int family, const double* z, const double* loc,
+                                   double loc_scalar, const double* cov, const double* obs, int64_t oh, int64_t ow,
+                                   double theta, int prior, int64_t H, int64_t W, int dim1, double* lp, double* grad_z,
+                                   double* grad_loc_sum, double* grad_cov, double* grad_theta) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    if (!z || !cov || !obs || !lp || !grad_z) return fail(c, GPT_ERR_SHAPE, "z, cov, obs, lp and grad_z must not be null");
+    if (oh < 1 || ow < 1 || oh > H || ow > W)
+        return fail(c, GPT_ERR_SHAPE, "the observed window must lie inside the lattice");
+    const int64_t Wf = W / 2 + 1;
+    Stager s(c, layout, arena_need(H, W, 8));
+    const double* dz = (const double*)s.up(z, H, W, 8);
+    const double* dc = (const double*)s.up(cov, H, Wf, 8);
+    const double* dob = (const double*)s.up(obs, oh, ow, 8);
+    const double* dl = (const double*)s.up(loc, H, W, 8);
+    double* dfill = loc ? nullptr : (double*)s.dev(H, W, 8);
+    double* dgz = (double*)s.dev(H, W, 8);
+    double* dgc = grad_cov ? (double*)s.dev(H, Wf, 8) : nullptr;
+    double* dsc = (double*)s.dev(1, 8, 8); // theta, lp, d/dloc sum, d/dtheta, min_eig
+    if (s.rc) return s.rc;
+    if (dfill) {
+        HIP_TRY(c, gpt_launch_fill(dfill, H * W, loc_scalar, c->stream));
+        dl = dfill;
+    }
+    c->pinned[1] = theta; // (slot 0 is the min_eig read-back of finish(); the stream is idle between calls)
+    HIP_TRY(c, hipMemcpyAsync(dsc, c->pinned + 1, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = gpt_gp_inv_rfft2_obs_lpdf_vjp(c, family, dz, 0, dl, 0, dc, 0, dob, 0, oh, ow,
+                                            family == GPT_OBS_POISSON_LOG ? nullptr : dsc, prior, H, W, 1, dim1, dsc + 1,
+                                            nullptr, dgz, nullptr, dsc + 2, dgc, dsc + 3, dsc + 4)))
+        return rc;
+    s.down(grad_z, dgz, H, W, 8);
+    s.down(grad_cov, dgc, H, Wf, 8);
+    s.down(lp, dsc + 1, 1, 1, 8);
+    s.down(grad_loc_sum, dsc + 2, 1, 1, 8);
+    if (family != GPT_OBS_POISSON_LOG) s.down(grad_theta, dsc + 3, 1, 1, 8);
+    else if (grad_theta) *grad_theta = 0.0;
+    return s.finish(dsc + 4);
+}
+
 int gpt_gp_rfft2_log_abs_det_jac_host(gpt_ctx* c, int layout, const double* cov, int64_t H, int64_t W, int dim1,
                                       double* out, double* grad_cov) {
     int rc = check_shape(c, H, W, 1, dim1);

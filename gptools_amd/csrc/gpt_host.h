@@ -108,3 +108,4 @@ int gpt_obs_blocks(int H, int W);
 hipError_t gpt_launch_obs(const ObsArgs& a, double* partials, hipStream_t st);
 hipError_t gpt_launch_obs_combine(const double* sums, const double* psum, int64_t batch, double* lp, double* grad_theta,
                                   double* grad_loc_sum, double* nobs, hipStream_t st);
+hipError_t gpt_launch_fill(double* p, int64_t n, double v, hipStream_t st);

@@ -55,6 +55,10 @@ __global__ void obs_combine_kernel(const double* sums, const double* psum, int64
     if (nobs) nobs[b] = sums[4 * b + 3];
 }
 
+__global__ void fill_kernel(double* p, int64_t n, double v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 } // namespace
 
 int gpt_obs_blocks(int H, int W) {
@@ -84,5 +88,14 @@ hipError_t gpt_launch_obs_combine(const double* sums, const double* psum, int64_
     if (batch <= 0) return hipSuccess;
     hipLaunchKernelGGL(obs_combine_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, sums, psum, batch, lp,
                        grad_theta, grad_loc_sum, nobs);
+    return hipGetLastError();
+}
+
+// rep_matrix(loc, H, W) of trees.stan:32 for callers that hold a scalar
+hipError_t gpt_launch_fill(double* p, int64_t n, double v, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    int64_t nb = (n + 1023) / 1024;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, n, v);
     return hipGetLastError();
 }

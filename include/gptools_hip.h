@@ -238,6 +238,15 @@ int gpt_gp_inv_rfft2_vjp_host(gpt_ctx*, int layout, const double* z, const doubl
 int gpt_gp_rfft2_vjp_host(gpt_ctx*, int layout, const double* y, const double* loc, const double* cov,
                           const double* zbar, int64_t height, int64_t width, int dim1, double* ybar,
                           double* covbar);
+/* Host-pointer form of gpt_gp_inv_rfft2_obs_lpdf_vjp for one lattice: what a `_lpmf`-style function of the Stan user
+ * header binds for docs/trees/trees.stan:31-49. `loc` NULL: the scalar `loc_scalar` everywhere (rep_matrix, trees.stan:32).
+ * `obs` is obs_h x obs_w in `layout`. Only z, cov and the data go up and only grad_z, grad_cov (may be NULL) and four
+ * scalars come down: the field f and d lp / d f stay on the device. GPT_ERR_NOT_PD as for the other host entry points. */
+int gpt_gp_inv_rfft2_obs_lpdf_host(gpt_ctx*, int layout, int family, const double* z, const double* loc,
+                                   double loc_scalar, const double* cov, const double* obs, int64_t obs_h,
+                                   int64_t obs_w, double theta, int prior, int64_t height, int64_t width, int dim1,
+                                   double* lp, double* grad_z, double* grad_loc_sum /* may be NULL */,
+                                   double* grad_cov /* may be NULL */, double* grad_theta /* may be NULL */);
 /* Real-FFT layer and layout helpers on host pointers (values only; the reference uses them in tests and
  * generated quantities): rfft/rfft2 (util.stan:263,302), inv_rfft/inv_rfft2 (util.stan:291,315),
  * expand_rfft (util.stan:271), gp_evaluate_rfft(2)_scale, gp_unpack_rfft(2), gp_pack_rfft(2). */

@@ -437,4 +437,53 @@ inline auto gp_periodic_matern_cov_rfft2(const T0__& nu, const int& height, cons
                                                                 });
 }
 
+// ---- extension: non-centred model density in one call (gptools/fft_obs.stan; include/gptools_hip.h,
+// gpt_gp_inv_rfft2_obs_lpdf_host). No counterpart in the reference, where docs/trees/trees.stan:31-49 spells the same
+// density as gp_inv_rfft2 + std_normal + a masked neg_binomial_2 loop. Only z, cov and the data travel to the GPU and
+// only the adjoints of z and cov (and four scalars) come back.
+namespace gptools_hip_detail {
+template <typename MAT, typename T0, typename TOBS, typename TLOC, typename TCOV, typename TTH>
+inline stan::return_type_t<T0, TLOC, TCOV, TTH> obs_lpdf(const T0& z, int family, const TOBS& obs, const TLOC& loc,
+                                                         const TCOV& cov, const TTH& theta, int prior, int dim1,
+                                                         const char* fn) {
+    const MAT zv = val(z), ov = val(obs), cv = val(cov);
+    const int64_t H = height_of(zv, dim1), W = width_of(zv, dim1);
+    const int64_t oh = height_of(ov, dim1), ow = width_of(ov, dim1);
+    if (cv.size() != H * (W / 2 + 1) || oh > H || ow > W || oh < 1 || ow < 1)
+        throw std::invalid_argument(std::string(fn) + ": argument sizes do not match");
+    const double lv = stan::math::value_of(loc), tv = stan::math::value_of(theta);
+    double value = 0.0, gls = 0.0, gth = 0.0;
+    stan::math::arena_t<MAT> gz(zv.rows(), zv.cols()), gc(cv.rows(), cv.cols());
+    check(gpt_gp_inv_rfft2_obs_lpdf_host(ctx(), GPT_COL_MAJOR, family, zv.data(), nullptr, lv, cv.data(), ov.data(), oh, ow,
+                                         tv, prior, H, W, dim1, &value, gz.data(), &gls,
+                                         stan::is_constant<TCOV>::value ? nullptr : gc.data(), &gth),
+          fn);
+    if constexpr (!any_var<T0, TLOC, TCOV, TTH>::value) {
+        return value;
+    } else {
+        auto arena_z = stan::math::to_arena(z);
+        auto arena_c = stan::math::to_arena(cov);
+        return stan::math::make_callback_var(value, [arena_z, arena_c, loc, theta, gz, gc, gls, gth](auto& vi) mutable {
+            if constexpr (!stan::is_constant<T0>::value) arena_z.adj() += vi.adj() * gz;
+            if constexpr (!stan::is_constant<TCOV>::value) arena_c.adj() += vi.adj() * gc;
+            add_adj(loc, vi.adj() * gls);
+            add_adj(theta, vi.adj() * gth);
+        });
+    }
+}
+}  // namespace gptools_hip_detail
+
+template <bool propto__, typename T0__, typename T2__, typename T3__, typename T4__, typename T5__>
+inline auto gp_inv_rfft2_obs_lpdf(const T0__& z, const int& family, const T2__& obs, const T3__& loc,
+                                  const T4__& cov_rfft2, const T5__& theta, const int& prior, std::ostream* pstream__) {
+    return gptools_hip_detail::obs_lpdf<Eigen::MatrixXd>(z, family, obs, loc, cov_rfft2, theta, prior, 0,
+                                                         "gp_inv_rfft2_obs_lpdf");
+}
+template <bool propto__, typename T0__, typename T2__, typename T3__, typename T4__, typename T5__>
+inline auto gp_inv_rfft_obs_lpdf(const T0__& z, const int& family, const T2__& obs, const T3__& loc,
+                                 const T4__& cov_rfft, const T5__& theta, const int& prior, std::ostream* pstream__) {
+    return gptools_hip_detail::obs_lpdf<Eigen::VectorXd>(z, family, obs, loc, cov_rfft, theta, prior, 1,
+                                                         "gp_inv_rfft_obs_lpdf");
+}
+
 #endif  // GPTOOLS_HIP_HPP

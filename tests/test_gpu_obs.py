@@ -192,3 +192,56 @@ def test_obs_rejects_bad_arguments(fft):
         fft.gp_inv_rfft2_obs_lpdf_vjp("poisson_log", z, None, cov, np.zeros((5, 6)))  # window taller than the lattice
     with pytest.raises(ValueError):
         fft.gp_inv_rfft2_obs_lpdf_vjp("normal", z, None, cov, np.zeros((4, 6)))  # no theta
+
+
+@pytest.mark.parametrize("layout", ["row", "col"])
+def test_obs_host_entry_point(fft, layout):
+    """gpt_gp_inv_rfft2_obs_lpdf_host: host pointers in the caller's layout (column-major = Stan / Eigen), scalar or
+    lattice loc, the trees docs shape and a 1-D model."""
+    import ctypes
+
+    from gptools_amd import _lib
+
+    lib = _lib.load()
+    ctx = fft.get_context()
+    rng = np.random.default_rng(19)
+    lay = _lib.GPT_COL_MAJOR if layout == "col" else _lib.GPT_ROW_MAJOR
+    A = (lambda a: np.asfortranarray(a)) if layout == "col" else (lambda a: np.ascontiguousarray(a))
+    P = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    cases = [(35, 60, 25, 50, 0, "neg_binomial_2_log", None), (12, 10, 12, 10, 0, "poisson_log", "lattice"),
+             (1, 128, 1, 100, 1, "normal", None), (256, 256, 200, 130, 0, "neg_binomial_2_log", "lattice")]
+    for (h, w, oh, ow, dim1, family, loc_kind) in cases:
+        wf = w // 2 + 1
+        z = rng.normal(size=(h, w))
+        cov = (o.gp_periodic_matern_cov_rfft2(1.5, h, w, 0.9, np.array([2.0, 3.0]), np.array([h, w])) + 1e-3 if not dim1
+               else (o.gp_periodic_exp_quad_cov_rfft(w, 1.1, 3.0, w) + 1e-3)[None])
+        obs, theta = _data(family, rng, (oh, ow), ())
+        loc = rng.normal(size=(h, w)) if loc_kind == "lattice" else None
+        loc_scalar = 0.0 if loc is not None else 0.35
+        th = float(theta) if theta is not None else 0.0
+        lp, gls, gth = np.zeros(1), np.zeros(1), np.zeros(1)
+        gz, gc = A(np.zeros((h, w))), A(np.zeros((h, wf)))
+        zA, covA, obsA, locA = A(z), A(cov), A(obs), (A(loc) if loc is not None else None)
+        rc = lib.gpt_gp_inv_rfft2_obs_lpdf_host(ctx.handle, lay, FAMILIES[family], P(zA), P(locA), loc_scalar, P(covA), P(obsA),
+                                                oh, ow, th, 1, h, w, dim1, P(lp), P(gz), P(gls), P(gc), P(gth))
+        assert rc == 0, ctx.error()
+        loc_full = loc if loc is not None else np.full((h, w), loc_scalar)
+        if dim1:
+            want = o.gp_inv_rfft_obs_lpdf_vjp(FAMILIES[family], z[0], loc_full[0], cov[0], obs[0], theta, True)
+            want = tuple(np.asarray(x)[None] if np.ndim(x) == 1 else x for x in want)
+        else:
+            want = o.gp_inv_rfft2_obs_lpdf_vjp(FAMILIES[family], z, loc_full, cov, obs, theta, True)
+        close(lp[0], want[0])
+        close(gz, want[2])
+        close(gls[0], want[4])
+        close(gc, want[5])
+        if theta is not None:
+            close(gth[0], want[6])
+    # a spectrum that is not positive definite is reported as the reference's reject (fft2.stan:21-23)
+    cov = np.ones((4, 4))
+    cov[1, 1] = -1.0
+    z, obs = np.zeros((4, 6)), np.zeros((4, 6))
+    lp, gz = np.zeros(1), np.zeros((4, 6))
+    rc = lib.gpt_gp_inv_rfft2_obs_lpdf_host(ctx.handle, _lib.GPT_ROW_MAJOR, 1, P(z), None, 0.0, P(cov), P(obs), 4, 6, 0.0, 0, 4,
+                                            6, 0, P(lp), P(gz), None, None, None)
+    assert rc == _lib.GPT_ERR_NOT_PD and "not positive-definite" in ctx.error()

@@ -52,3 +52,18 @@ def test_compile_model_needs_cmdstanpy_but_import_does_not():
     except ImportError:
         with pytest.raises(ImportError, match="cmdstanpy"):
             stan.compile_model(stan_file="does_not_matter.stan")
+
+
+def test_observation_model_extension_is_declared_and_bound():
+    """gptools/fft_obs.stan (an opt-in extension, not a reference file) and its definitions in the user header."""
+    from gptools_amd import stan
+
+    inc = stan.get_include()
+    text = open(os.path.join(inc, "gptools", "fft_obs.stan")).read()
+    hpp = open(stan.get_user_header()).read()
+    for fn in ("gp_inv_rfft2_obs_lpdf", "gp_inv_rfft_obs_lpdf"):
+        assert re.search(rf"^real {fn}\(", text, re.M), fn
+        assert re.search(rf"inline auto {fn}\(", hpp), fn
+    assert "gpt_gp_inv_rfft2_obs_lpdf_host" in hpp
+    # the reference's own include names stay free of the extension: existing models compile unchanged
+    assert "fft_obs" not in open(os.path.join(inc, "gptools", "fft.stan")).read()
