@@ -32,10 +32,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def synthetic(fft, size, batch, device, seed):
-    """SURVEY 8(d) recipe: Matern-3/2 spectrum + nugget, y = gp_inv_rfft2(z, loc, c) with z ~ N(0, 1)."""
+def synthetic(fft, size, batch, device, seed, per_lattice_cov=False):
+    """SURVEY 8(d) recipe: Matern-3/2 spectrum + nugget, y = gp_inv_rfft2(z, loc, c) with z ~ N(0, 1). The spectrum
+    is shared by the batch, or (the recipe's second run) one per lattice from per-lattice sigma_b, length_scale_b."""
     h = w = size
-    cov = fft.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.3, [8.0, 12.0], [float(h), float(w)]) + 1e-3
+    if per_lattice_cov:
+        b = torch.arange(batch, dtype=torch.float64, device=device)
+        sigma = 1.3 + 0.05 * b
+        ls = torch.stack([8.0 + 0.25 * b, 12.0 + 0.25 * b], dim=-1)
+        cov = fft.gp_periodic_matern_cov_rfft2(1.5, h, w, sigma, ls, [float(h), float(w)]) + 1e-3
+    else:
+        cov = fft.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.3, [8.0, 12.0], [float(h), float(w)]) + 1e-3
     g = torch.Generator(device=device)
     g.manual_seed(7)
     loc = torch.randn(h, w, dtype=torch.float64, device=device, generator=g)
@@ -148,6 +155,9 @@ def main():
                     help="not the headline: ONE lattice of --size split over all ranks (row / column slabs, "
                          "all-to-all over RCCL), strong scaling")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-pass HIP-event timing")
+    ap.add_argument("--per-lattice-cov", action="store_true",
+                    help="not the headline: one spectrum per lattice (per-lattice sigma, length_scale) instead of a "
+                         "spectrum shared by the batch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,7 +188,7 @@ def main():
     h = w = size
     n = h * w
     hwf = h * (w // 2 + 1)
-    y, loc, cov = synthetic(fft, size, B, device, seed=rank)
+    y, loc, cov = synthetic(fft, size, B, device, seed=rank, per_lattice_cov=args.per_lattice_cov)
     lp = torch.empty(B, dtype=torch.float64, device=device)
     mn = torch.empty(B, dtype=torch.float64, device=device)
     gy = torch.empty_like(y)
@@ -245,7 +255,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"synthetic {size}x{size} lattice gp_rfft2_lpdf + gradients (d/dy, d/dcov), "
-                        f"batch of {B} lattices per GPU per step, cov/loc shared by the batch",
+                        f"batch of {B} lattices per GPU per step, "
+                        + ("loc shared by the batch, one cov per lattice" if args.per_lattice_cov
+                           else "cov/loc shared by the batch"),
             "global_batch": world * B,
             "parallelism": f"independent lattices sharded over {world} GPU(s), no collective",
             "path": fft.path_for_shape(h, w),
