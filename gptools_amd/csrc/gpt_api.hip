@@ -1072,6 +1072,10 @@ int gpt_gp_inv_rfft2_obs_lpdf_host(gpt_ctx* c, int layout, int family, const dou
     if (!z || !cov || !obs || !lp || !grad_z) return fail(c, GPT_ERR_SHAPE, "z, cov, obs, lp and grad_z must not be null");
     if (oh < 1 || ow < 1 || oh > H || ow > W)
         return fail(c, GPT_ERR_SHAPE, "the observed window must lie inside the lattice");
+    // Stan Math rejects these (normal_lpdf: "Scale parameter", neg_binomial_2_lpmf: "Precision parameter")
+    if (family != GPT_OBS_POISSON_LOG && !(theta > 0 && std::isfinite(theta)))
+        return fail(c, GPT_ERR_SHAPE, family == GPT_OBS_NORMAL ? "Scale parameter must be positive finite"
+                                                               : "Precision parameter must be positive finite");
     const int64_t Wf = W / 2 + 1;
     Stager s(c, layout, arena_need(H, W, 8));
     const double* dz = (const double*)s.up(z, H, W, 8);

@@ -241,7 +241,9 @@ int gpt_gp_rfft2_vjp_host(gpt_ctx*, int layout, const double* y, const double* l
 /* Host-pointer form of gpt_gp_inv_rfft2_obs_lpdf_vjp for one lattice: what a `_lpmf`-style function of the Stan user
  * header binds for docs/trees/trees.stan:31-49. `loc` NULL: the scalar `loc_scalar` everywhere (rep_matrix, trees.stan:32).
  * `obs` is obs_h x obs_w in `layout`. Only z, cov and the data go up and only grad_z, grad_cov (may be NULL) and four
- * scalars come down: the field f and d lp / d f stay on the device. GPT_ERR_NOT_PD as for the other host entry points. */
+ * scalars come down: the field f and d lp / d f stay on the device. GPT_ERR_NOT_PD as for the other host entry points;
+ * GPT_ERR_SHAPE for a scale / precision that is not positive and finite (Stan Math rejects those). The device entry
+ * point cannot look at theta without a synchronisation: there such a value yields NaN. */
 int gpt_gp_inv_rfft2_obs_lpdf_host(gpt_ctx*, int layout, int family, const double* z, const double* loc,
                                    double loc_scalar, const double* cov, const double* obs, int64_t obs_h,
                                    int64_t obs_w, double theta, int prior, int64_t height, int64_t width, int dim1,

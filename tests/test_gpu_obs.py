@@ -245,3 +245,8 @@ def test_obs_host_entry_point(fft, layout):
     rc = lib.gpt_gp_inv_rfft2_obs_lpdf_host(ctx.handle, _lib.GPT_ROW_MAJOR, 1, P(z), None, 0.0, P(cov), P(obs), 4, 6, 0.0, 0, 4,
                                             6, 0, P(lp), P(gz), None, None, None)
     assert rc == _lib.GPT_ERR_NOT_PD and "not positive-definite" in ctx.error()
+    # a non-positive scale / precision is an argument error, as in Stan Math
+    cov = np.ones((4, 4))
+    rc = lib.gpt_gp_inv_rfft2_obs_lpdf_host(ctx.handle, _lib.GPT_ROW_MAJOR, 2, P(z), None, 0.0, P(cov), P(obs), 4, 6, -1.0, 0,
+                                            4, 6, 0, P(lp), P(gz), None, None, None)
+    assert rc == _lib.GPT_ERR_SHAPE and "Precision" in ctx.error()
