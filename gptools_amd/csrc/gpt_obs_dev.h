@@ -94,11 +94,28 @@ template <int FAM> __device__ __forceinline__ ObsTerm obs_term(double y, double 
         // k[0] = log(phi), k[1] = lgamma(phi), k[2] = digamma(phi)
         const double lse = log_sum_exp2(f, k[0]); // log(mu + phi)
         const double npf = y + th;
-        double lg, dg;
-        lgamma_digamma_pos(npf, lg, dg);
-        t.lp = lg - log_factorial(y) - k[1] + y * (f - lse) + th * (k[0] - lse);
+        // lgamma(y + phi) - lgamma(phi) and digamma(y + phi) - digamma(phi)
+        double lgd, dgd;
+        if (y <= 32.0 && y == floor(y)) {
+            // small counts (nearly all of such data): the rising product phi (phi + 1) ... (phi + y - 1) and its
+            // derivative -- one logarithm and one division, and no cancellation between two large values
+            double p = 1.0, dp = 0.0, x = th;
+            for (int i = (int)y; i > 0; --i) {
+                dp = fma(dp, x, p);
+                p *= x;
+                x += 1.0;
+            }
+            lgd = log(p);
+            dgd = dp / p;
+        } else {
+            double lg, dg;
+            lgamma_digamma_pos(npf, lg, dg);
+            lgd = lg - k[1];
+            dgd = dg - k[2];
+        }
+        t.lp = lgd - log_factorial(y) + y * (f - lse) + th * (k[0] - lse);
         t.df = y - npf * exp(f - lse);
-        t.dth = dg - k[2] + k[0] - lse + 1.0 - npf * exp(-lse);
+        t.dth = dgd + k[0] - lse + 1.0 - npf * exp(-lse);
     }
     return t;
 }
