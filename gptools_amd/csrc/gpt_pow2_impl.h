@@ -396,10 +396,13 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
     constexpr int T = Geo<W>::T, LINES = Geo<W>::ROW_LINES;
     const int line = threadIdx.x / T, t = threadIdx.x - line * T;
     double* lds = reinterpret_cast<double*>(smem) + (size_t)line * W;
-    const int64_t b = blockIdx.y;
+    // Workgroups are dispatched x-fastest: numbering them lattice-fastest puts the same rows of all the lattices of
+    // a launch next to each other in time, so a loc (and the twiddles) shared by the batch is read from HBM once.
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int64_t b = lin % gridDim.y;
     const int H = a.H;
     const int npairs = H / 2;
-    const int r = blockIdx.x * LINES + line; // row pair
+    const int r = (int)(lin / gridDim.y) * LINES + line; // row pair
     const bool active = r < npairs;
     const int rr = active ? r : 0;
     const double* src = in_mode == 2 ? a.aux + b * a.aux_bs : a.x + b * a.x_bs;
