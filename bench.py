@@ -283,8 +283,9 @@ def main():
         }
         if profile and launches.value > 0:
             per_eval = [1e-3 * pass_ms[k] / (B * prof_steps) for k in range(4)]  # seconds per evaluation
+            lpl = B * prof_steps / launches.value  # lattices per launch: the shared loc is read once per launch
             pass_bytes = {
-                "row_fwd (pass A)": 16 * n + 8 * n,        # read y, loc; write packed spectrum
+                "row_fwd (pass A)": 16 * n + int(8 * n / lpl),  # read y, loc (shared); write packed spectrum
                 "col (pass B)": 8 * n + 8 * hwf + 8 * hwf + 8 * n,  # spectrum r/w in place, read c, write dcov
                 "finalize": 0,
                 "row_inv (pass C)": 8 * n + 8 * n,         # read spectrum, write d/dy
@@ -294,8 +295,11 @@ def main():
                 kernels.append({"name": name, "avg_ms_per_eval": 1e3 * sec, "compulsory_bytes": nbytes,
                                 "GBps": (nbytes / sec / 1e9) if sec > 0 and nbytes else None})
             result["roofline"]["kernels"] = kernels
+            result["roofline"]["lattices_per_launch"] = lpl
             result["roofline"]["kernels_note"] = (f"average launch durations over {prof_steps} extra untimed steps "
-                                                  "with per-pass HIP events inside the library")
+                                                  "with per-pass HIP events inside the library, divided by the "
+                                                  f"{lpl:g} lattices a launch processes (rocprofv3's per-launch "
+                                                  "averages are that many times larger)")
             dom = max(kernels, key=lambda k: k["avg_ms_per_eval"])
             result["roofline"]["dominant_kernel"] = {"name": dom["name"], "GBps": dom["GBps"],
                                                      "frac": dom["GBps"] * 1e9 / HBM_PEAK}
