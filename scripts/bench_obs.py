@@ -22,7 +22,7 @@ def main():
     loc = torch.full((H, W), 0.5, dtype=torch.float64, device=dev)
     need_f = os.environ.get("OBS_NEED_F", "1") != "0"
     for family in os.environ.get("OBS_FAMILIES", "neg_binomial_2_log,poisson_log,normal").split(","):
-        for B in (1, 4):
+        for B in [int(v) for v in os.environ.get("OBS_BATCHES", "1,4").split(",")]:
             z = torch.randn(B, H, W, dtype=torch.float64, device=dev, generator=g)
             obs = torch.poisson(torch.full((oh, ow), 2.0, dtype=torch.float64, device=dev), generator=g)
             obs[torch.rand(oh, ow, device=dev, generator=g) < 0.1] = -1.0 if family != "normal" else float("nan")
