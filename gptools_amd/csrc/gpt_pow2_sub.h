@@ -165,7 +165,7 @@ __device__ __forceinline__ void col0_role(const LatArgs& a, const ZLayout& L, co
 template <int HS, int V, int THREADS, int OP>
 __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2))  // waves per SIMD the register budget must allow
     colsub_kernel(LatArgs a, int R, cplx* __restrict__ ws, int wstride, const cplx* __restrict__ tws,
-                  double* __restrict__ partials, int ntq, double* __restrict__ edge, int edge_flags, int nact) {
+                  double* __restrict__ partials, int ntq, double* __restrict__ edge, int edge_flags, int npart) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = GeoS<HS, V, THREADS>;
     constexpr int T = G::T, TC = G::TC, TP = G::TP;
@@ -206,12 +206,8 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
     const int ntiles = R * ntq;
     int first, step, count;
     {
-        // the grid is as large as the lattice's partials; the first nact workgroups share the tiles (geometries
-        // that fit fewer workgroups on a CU), the others only write their neutral partial
-        const int nwg = nact, bid = blockIdx.x;
-        if (bid >= nact) {
-            first = step = count = 0;
-        } else if ((nwg & 7) == 0 && (ntiles & 7) == 0) {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        if ((nwg & 7) == 0 && (ntiles & 7) == 0) {
             const int per = ntiles >> 3, i = bid >> 3;
             step = nwg >> 3;
             first = (bid & 7) * per + i;
@@ -391,13 +387,20 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
         }
         block_sum_min(s, mn, red);
         if (threadIdx.x == 0) {
-            double* p = partials + ((int64_t)b * gridDim.x + blockIdx.x) * GPT_PART;
+            // a lattice has npart partial slots, whatever the grid of this geometry: the surplus ones get the
+            // neutral element
+            double* p = partials + ((int64_t)b * npart + blockIdx.x) * GPT_PART;
             p[0] = s;
             p[1] = op_is_kvjp(OP) ? kk[0] : 0.0;
             p[2] = op_is_kvjp(OP) ? kk[1] : 0.0;
             p[3] = op_is_kvjp(OP) ? kk[2] : 0.0;
             p[4] = 0.0;
             p[5] = mn;
+            for (int k = blockIdx.x + gridDim.x; k < npart; k += gridDim.x) {
+                double* q = partials + ((int64_t)b * npart + k) * GPT_PART;
+                q[0] = q[1] = q[2] = q[3] = q[4] = 0.0;
+                q[5] = INFINITY;
+            }
         }
     }
 }
