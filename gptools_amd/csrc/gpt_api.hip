@@ -180,7 +180,12 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
         if (big < 1) big = 1;
         const int64_t nunits = (a.batch + big - 1) / big;
         big = (a.batch + nunits - 1) / nunits; // units of equal size
-        if (per * (size_t)big >= ((size_t)1536 << 20)) chunk = big;
+        static const size_t unit_min = [] { // GPT_UNIT_MIN_MIB: smallest unit worth giving up cache residency for
+            const char* e = getenv("GPT_UNIT_MIN_MIB");
+            const long v = e ? atol(e) : 0;
+            return (size_t)(v > 0 ? v : 1536) << 20;
+        }();
+        if (per * (size_t)big >= unit_min) chunk = big;
     }
     if (chunk > a.batch) chunk = a.batch;
     if (chunk > 32768) chunk = 32768;
