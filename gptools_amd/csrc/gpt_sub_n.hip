@@ -86,13 +86,13 @@ hipError_t LaunchSub<GPT_N>::line_fft(bool inverse, cplx* data, int64_t nlines, 
 constexpr bool op_z_layout(int op) {
     return op == OP_GP_RFFT2 || op == OP_GP_INV_RFFT2 || op == OP_INV_VJP || op == OP_FWD_VJP;
 }
-template <int OP, int THREADS>
+template <int OP, int THREADS, bool NT = false>
 static hipError_t colsub_g(const LatArgs& a, int R, cplx* ws, int wstride, const cplx* tws, double* partials, int nwg,
                            double* edge, int edge_flags, hipStream_t st) {
     constexpr int HS = GPT_N;
     using G = GeoS<HS, SUB_V, THREADS>;
     const size_t lds = G::lds_bytes();
-    hipError_t e = raise_lds_sub(colsub_kernel<HS, SUB_V, THREADS, OP>, lds);
+    hipError_t e = raise_lds_sub(colsub_kernel<HS, SUB_V, THREADS, OP, NT>, lds);
     if (e != hipSuccess) return e;
     const int ncols = a.ncols > 0 ? a.ncols : a.W / 2;
     if (ncols % G::TC != 0) return hipErrorInvalidValue;
@@ -103,7 +103,7 @@ static hipError_t colsub_g(const LatArgs& a, int R, cplx* ws, int wstride, const
     if (THREADS != SUB_THREADS && SUB_WGS_PER_CU == 2 && nwg >= 16) nact = (nwg / 2) & ~7;
     if (nact < R / 2 + 1) nact = nwg;
     dim3 grid((unsigned)nact, (unsigned)a.batch);
-    hipLaunchKernelGGL((colsub_kernel<HS, SUB_V, THREADS, OP>), grid, dim3(THREADS), lds, st, a, R, ws, wstride, tws,
+    hipLaunchKernelGGL((colsub_kernel<HS, SUB_V, THREADS, OP, NT>), grid, dim3(THREADS), lds, st, a, R, ws, wstride, tws,
                        partials, ntq, edge, edge_flags, nwg);
     return hipGetLastError();
 }
@@ -116,8 +116,9 @@ static hipError_t colsub_t(const LatArgs& a, int R, cplx* ws, int wstride, const
     // the real z layout, and for every op when the launch's workspace cannot be cache-resident (units of many
     // lattices, gpt_api.hip): 4096^2 column pass 124.5 -> 118 us there, but 123 -> 130 us on a warm workspace.
     const bool cold = (size_t)a.batch * (size_t)a.H * (size_t)wstride * sizeof(cplx) > ((size_t)256 << 20);
-    if (op_z_layout(OP) || cold)
-        return colsub_g<OP, 512>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    if (cold) // ... and streams the workspace past the caches
+        return colsub_g<OP, 512, true>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    if (op_z_layout(OP)) return colsub_g<OP, 512>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
 #endif
     return colsub_g<OP, SUB_THREADS>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
 }
