@@ -384,12 +384,25 @@ template <int N> struct Geo {
     static constexpr int SKEW = TC == 4 ? 4 : 8;          // ... and the offset between its columns' regions
 };
 
+// Workspace stores of pass A. NTS: non-temporal, for launches whose workspace cannot be cache-resident (units of many
+// lattices): the streamed lines leave the Infinity Cache to what is reused (4096^2 x 16: +3 %). Non-temporal LOADS of
+// the workspace in pass C were measured too and lose (row_inv 53 -> 70 us).
+typedef double gpt_rd2v __attribute__((ext_vector_type(2)));
+template <bool NTS> __device__ __forceinline__ void rows_st(cplx* p, cplx v) {
+    if (NTS) {
+        const gpt_rd2v t = {v.x, v.y};
+        __builtin_nontemporal_store(t, reinterpret_cast<gpt_rd2v*>(p));
+    } else {
+        *p = v;
+    }
+}
+
 // pass A --------------------------------------------------------------------------------------------
 // in_mode: 0 = x, 1 = x - loc, 2 = aux
 // SUB2 (sub-line variant with R = 2, gpt_pow2_sub.h): the workgroup's two rows are r and r + H/2 instead of
 // 2r and 2r + 1, and the first radix-2 step of the column transform is done on them before they are stored:
 // u0 = S[r] + S[r + H/2] -> workspace row r, u1 = (S[r] - S[r + H/2]) w_H^r -> workspace row H/2 + r.
-template <int W, bool SUB2 = false>
+template <int W, bool SUB2 = false, bool NTS = false>
 __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a, int in_mode, cplx* __restrict__ ws,
                                                                       int wstride, double* __restrict__ edge) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -489,11 +502,11 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
             zb = make_double2(0.5 * (z.y + zc[m].y), -0.5 * (z.x - zc[m].x));
         }
         if (SUB2) {
-            s0[j] = cadd(za, zb);
-            s1[j] = cmul(csub(za, zb), wr);
+            rows_st<NTS>(&s0[j], cadd(za, zb));
+            rows_st<NTS>(&s1[j], cmul(csub(za, zb), wr));
         } else {
-            s0[j] = za;
-            s1[j] = zb;
+            rows_st<NTS>(&s0[j], za);
+            rows_st<NTS>(&s1[j], zb);
         }
     }
     if (pf) asm volatile("" ::"v"(pf0), "v"(pf1)); // keeps the touches; they have long arrived

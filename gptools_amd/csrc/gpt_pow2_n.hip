@@ -20,22 +20,30 @@ template <typename K> hipError_t raise_lds(K kernel, size_t lds) {
 }
 } // namespace
 
-template <>
-hipError_t Launch<GPT_N>::row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, bool sub2,
-                                  hipStream_t st) {
+namespace {
+template <bool SUB2, bool NTS>
+hipError_t row_fwd_g(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, hipStream_t st) {
     constexpr int W = GPT_N;
     const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(double);
-    hipError_t e = sub2 ? raise_lds(row_fwd_kernel<W, true>, lds) : raise_lds(row_fwd_kernel<W, false>, lds);
+    hipError_t e = raise_lds(row_fwd_kernel<W, SUB2, NTS>, lds);
     if (e != hipSuccess) return e;
     const int npairs = a.H / 2;
     dim3 grid((npairs + Geo<W>::ROW_LINES - 1) / Geo<W>::ROW_LINES, (unsigned)a.batch);
-    if (sub2)
-        hipLaunchKernelGGL((row_fwd_kernel<W, true>), grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, in_mode, ws, wstride,
-                           edge);
-    else
-        hipLaunchKernelGGL((row_fwd_kernel<W, false>), grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, in_mode, ws, wstride,
-                           edge);
+    hipLaunchKernelGGL((row_fwd_kernel<W, SUB2, NTS>), grid, dim3(Geo<W>::ROW_THREADS), lds, st, a, in_mode, ws, wstride,
+                       edge);
     return hipGetLastError();
+}
+} // namespace
+
+template <>
+hipError_t Launch<GPT_N>::row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, bool sub2,
+                                  hipStream_t st) {
+    // a workspace beyond the Infinity Cache is streamed past it (see rows_st)
+    const bool cold = (size_t)a.batch * (size_t)a.H * (size_t)wstride * sizeof(cplx) > ((size_t)256 << 20);
+    if (cold) return sub2 ? row_fwd_g<true, true>(a, in_mode, ws, wstride, edge, st)
+                          : row_fwd_g<false, true>(a, in_mode, ws, wstride, edge, st);
+    return sub2 ? row_fwd_g<true, false>(a, in_mode, ws, wstride, edge, st)
+                : row_fwd_g<false, false>(a, in_mode, ws, wstride, edge, st);
 }
 
 template <>
