@@ -14,12 +14,16 @@ the operator (24 n + 16 H (W/2+1) bytes per evaluation) u
 measured with HIP events inside the library (gpt_profile_begin/end), and lists every pass with its own
 compulsory bytes so the numbers can be held against the rocprofv3 summary under profiles/.
 `cpu_baseline` times the CPU oracle (oracle/gp_oracle.py, NumPy restatement of the reference) on the host
-cores of the same box, rank 0 and N == 1 only, on a bounded sample.
+cores of the same box (one core, and one process per core of the box's CPU share), rank 0 and N == 1 only, on a
+bounded sample. `python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run as a
+child process); under a launcher (WORLD_SIZE set) it is one of the ranks. `n_gpus` is the size of the process group.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -63,31 +67,40 @@ def pmc_traffic(size):
         return None
 
 
-def cpu_baseline(size, budget_s=20.0):
-    """Oracle (NumPy port of the reference maths, 1 core) on a bounded sample of the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import gp_oracle as oracle
+def cpu_baseline(size, budget_s=10.0):
+    """The CPU oracle (oracle/gp_oracle.py, NumPy restatement of the reference) on this box's host cores: one core, and
+    one process per core of the box's CPU share. Runs as a child process (oracle/cpu_baseline.py: no torch, no GPU)."""
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--size", str(size), "--budget", str(budget_s)]
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240, check=True)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except (subprocess.SubprocessError, ValueError, IndexError) as exc:
+        return {"value": None, "unit": "evals/s", "cores": 0, "kind": "port", "sample": f"cpu baseline failed: {exc}"}
 
-    rng = np.random.default_rng(0)
-    h = w = size
-    cov = oracle.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.3, [8.0, 12.0], [float(h), float(w)]) + 1e-3
-    loc = rng.normal(size=(h, w))
-    y = rng.normal(size=(h, w))
-    n_done, t0 = 0, time.perf_counter()
-    while True:
-        oracle.gp_rfft2_lpdf_vjp(y, loc, cov)
-        n_done += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n_done >= 8:
-            break
-    return {
-        "value": n_done / el,
-        "unit": "evals/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{n_done} evaluations of gp_rfft2_lpdf+grad at {size}x{size} with oracle/gp_oracle.py "
-                  f"(NumPy pocketfft, single thread) in {el:.1f} s",
-    }
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU, RCCL) as a child job of
+    torch.distributed.run -- before this process has touched the GPU -- relay rank 0's JSON line, and exit with the
+    job's status."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {n}-rank job failed (exit status {proc.returncode})", file=sys.stderr)
+        sys.exit(proc.returncode or 1)
+    print(line)
+    sys.exit(0)
 
 
 def slab_bench(args, fft, device, world, rank, distributed):
@@ -143,6 +156,78 @@ def slab_bench(args, fft, device, world, rank, distributed):
         dist.destroy_process_group()
 
 
+def dry_run(args, world, rank):
+    """CPU rehearsal of the multi-rank plumbing (tests/test_bench_launch.py): launcher, rendezvous (gloo), barrier,
+    max-over-ranks clock and the JSON line -- no GPU, no kernels, and flagged so that it cannot pass for a measurement."""
+    import torch.distributed as dist
+
+    from gptools_amd import sharding
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    if os.environ.get("GPT_BENCH_FAIL_RANK") == str(rank):  # (test hook: a rank that dies takes the job down)
+        sys.exit(3)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
+    n_ranks = dist.get_world_size() if world > 1 else 1
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "gp_rfft2_lpdf+grad evals/sec (fp64, 4096^2)", "value": None, "unit": "evals/s",
+                          "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f64", "data": "none", "dry_run": True,
+                          "config": {"workload": "DRY RUN: no kernels were launched", "global_batch": n_ranks * args.batch}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def self_check(fft, y, loc, cov, out, per_lattice_cov):
+    """Outside the timed region: the last lattice of the timed batch against a single-lattice call of the same entry
+    point (a different launch geometry, tests/test_gpu_headline_batch.py holds both to the oracle)."""
+    lp, gy, gc, _ = out
+    i = y.shape[0] - 1
+    lp1, gy1, gc1 = fft.gp_rfft2_lpdf_vjp(y[i], loc, cov[i] if per_lattice_cov else cov, check=False)
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max())
+
+    errs = {"lpdf": rel(lp[i:i + 1], lp1.reshape(1)), "grad_y": rel(gy[i], gy1), "grad_cov": rel(gc[i], gc1)}
+    assert max(errs.values()) < 1e-12, f"timed batch disagrees with the single-lattice call: {errs}"
+    return errs
+
+
+def fused_kernel_extra(fft, y, loc, steps):
+    """NOT the headline: the kernel-fused entry point (gpt_gp_rfft2_lpdf_kernel_vjp) on the same
+    lattices; its own algorithmic bytes: read y, loc, write d/dy = 24 n (no spectrum, no d/dcov in memory)."""
+    B, h, w = y.shape
+    sigma = torch.full((B,), 1.3, dtype=torch.float64, device=y.device)
+    ls = torch.tensor([8.0, 12.0], dtype=torch.float64, device=y.device).expand(B, 2)
+    per = torch.tensor([float(h), float(w)], dtype=torch.float64, device=y.device).expand(B, 2)
+
+    def step():
+        return fft.gp_rfft2_lpdf_kernel_vjp(y, loc, "matern", 1.5, sigma, ls, per, nugget=1e-3, check=False)
+
+    step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        lp, _, _ = step()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = 1e-3 * e0.elapsed_time(e1) / (steps * B)
+    b_alg = 24 * h * w
+    return {"entry_point": "gpt_gp_rfft2_lpdf_kernel_vjp (Matern-3/2 + nugget evaluated inside the column pass)",
+            "evals_per_s": 1.0 / sec, "algorithmic_bytes_per_eval": b_alg, "achieved_GBps": b_alg / sec / 1e9,
+            "frac": b_alg / sec / HBM_PEAK, "finite": bool(torch.isfinite(lp).all()),
+            "note": "allocates its outputs inside the timed loop (shim convenience path)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,14 +240,26 @@ def main():
                     help="not the headline: ONE lattice of --size split over all ranks (row / column slabs, "
                          "all-to-all over RCCL), strong scaling")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-pass HIP-event timing")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra (non-headline) kernel-fused measurement")
     ap.add_argument("--per-lattice-cov", action="store_true",
                     help="not the headline: one spectrum per lattice (per-lattice sigma, length_scale) instead of a "
                          "spectrum shared by the batch")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the multi-rank plumbing only (gloo, no GPU, no kernels, value null)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` (no launcher): this process only starts the N ranks and relays their line. Nothing
+    # here has touched the GPU yet (importing torch does not).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
@@ -176,6 +273,7 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()  # what the job really is
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
@@ -232,9 +330,12 @@ def main():
     barrier()
     elapsed = sharding.max_over_ranks(elapsed, device=device)  # the job's clock is its slowest rank
 
-    # sanity of what was computed in the timed region (not timed): finite values, PD check passed
+    # what was computed in the timed region (not timed): finite values, PD check passed, and the last lattice of the
+    # batch equal to a single-lattice evaluation
+    check_errs = None
     if not os.environ.get("GPT_BENCH_NOCHECK"):  # timing-only experiment builds compute garbage on purpose
         assert bool(torch.isfinite(lp).all()) and float(mn.min()) >= 0.0, "benchmark produced invalid results"
+        check_errs = self_check(fft, y, loc, cov, out, args.per_lattice_cov)
 
     evals = world * B * args.steps
     value = evals / elapsed
@@ -253,6 +354,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
+        "checked": check_errs is not None,
+        "check": {"what": "last lattice of the timed batch vs a single-lattice call, max relative error",
+                  "errors": check_errs},
         "config": {
             "workload": f"synthetic {size}x{size} lattice gp_rfft2_lpdf + gradients (d/dy, d/dcov), "
                         f"batch of {B} lattices per GPU per step, "
@@ -316,6 +420,8 @@ def main():
             torch.cuda.synchronize()
             result["roofline"]["measured_copy_GBps"] = 10 * 2 * src.numel() * 8 / (1e-3 * c0.elapsed_time(c1)) / 1e9
             del src, dst
+        if world == 1 and not args.no_extra:
+            result["extra"] = {"kernel_fused_lpdf": fused_kernel_extra(fft, y, loc, max(2, min(args.steps, 5)))}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(size)
         print(json.dumps(result))

@@ -219,13 +219,7 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
             HIP_TRY(c, gpt_launch_generic(op, s, c->ws, c->partials, c->stream));
             continue;
         }
-        // GPT_DEBUG_PASSES=<bitmask> (timing experiments only: wrong results): run only the passes whose bit is set
-        static const int pass_mask = [] {
-            const char* e = getenv("GPT_DEBUG_PASSES");
-            return e ? atoi(e) : 7;
-        }();
         for (int pass = 0; pass < 3; ++pass) {
-            if (!((pass_mask >> pass) & 1)) continue;
             // each pass bracketed by timing events in profiling mode
             const bool present = pass == 1 || (pass == 0 ? op_has_fwd(op) : op_has_inv(op));
             gpt_ctx::ProfRec pr = {nullptr, nullptr, pass == 2 ? 3 : pass};
@@ -980,6 +974,12 @@ struct Stager {
     size_t off = 0;
     int layout;
     int rc = GPT_OK;
+    bool drained = false;
+    // Every exit of a host entry point, early error returns included, leaves no copy from or to the caller's
+    // (pageable) arrays in flight.
+    ~Stager() {
+        if (!drained) (void)hipStreamSynchronize(c->stream);
+    }
     Stager(gpt_ctx* ctx, int lay, size_t need) : c(ctx), layout(lay) {
         if (hipSetDevice(c->device) != hipSuccess) {
             rc = fail(c, GPT_ERR_HIP, "hipSetDevice failed");
@@ -1032,6 +1032,7 @@ struct Stager {
         }
         hipError_t e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return hip_fail(c, e, "hipStreamSynchronize");
+        drained = true;
         if (d_min_eig) {
             mn = c->pinned[0];
             c->last_min_eig = mn;

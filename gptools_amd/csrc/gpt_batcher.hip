@@ -86,8 +86,13 @@ void run_batch(gpt_batcher* b) {
         if (!download(b, b->h_lp, b->d_lp, 1, 1) || !download(b, b->h_mn, b->d_mn, 1, 1)) break;
         if (b->want_gy && !download(b, b->h_gy, b->d_gy, b->H, b->W)) break;
         if (b->want_gy && b->want_gc && !download(b, b->h_gc, b->d_gc, b->H, Wf)) break;
-        ok(b, hipStreamSynchronize(b->stream), "hipStreamSynchronize");
     } while (false);
+    // on every exit, failed rounds included: the pinned staging areas are rewritten by the chains as soon as they
+    // wake, so no copy of this round may still be in flight
+    {
+        const hipError_t e = hipStreamSynchronize(b->stream);
+        if (b->batch_rc == GPT_OK) ok(b, e, "hipStreamSynchronize");
+    }
     b->launches++;
     b->want_gy = b->want_gc = false;
     b->arrived = 0;
@@ -158,7 +163,13 @@ int gpt_batcher_lpdf_host(gpt_batcher* b, int slot, const double* y, const doubl
                           double* lpdf, double* grad_y, double* grad_cov) {
     if (!b || slot < 0 || slot >= b->nslots || !y || !cov || !lpdf || (grad_cov && !grad_y)) return GPT_ERR_SHAPE;
     const size_t hw = (size_t)b->hw, hwf = (size_t)b->hwf;
-    // the slot's staging area is private to the calling chain until it arrives
+    {
+        // a slot that has left holds benign data that a running batch may be uploading: it must not be written
+        std::unique_lock<std::mutex> lk(b->m);
+        if (!b->active[(size_t)slot]) return GPT_ERR_SHAPE;
+    }
+    // The staging area of an ACTIVE slot is private to its chain until the chain arrives: a batch runs only once
+    // every active slot has arrived, this one included.
     memcpy(b->h_y + slot * hw, y, sizeof(double) * hw);
     if (loc) memcpy(b->h_loc + slot * hw, loc, sizeof(double) * hw);
     else memset(b->h_loc + slot * hw, 0, sizeof(double) * hw);
@@ -166,7 +177,6 @@ int gpt_batcher_lpdf_host(gpt_batcher* b, int slot, const double* y, const doubl
     int rc;
     {
         std::unique_lock<std::mutex> lk(b->m);
-        if (!b->active[(size_t)slot]) return GPT_ERR_SHAPE; // the slot has left
         b->want_gy = b->want_gy || grad_y != nullptr;
         b->want_gc = b->want_gc || grad_cov != nullptr;
         const unsigned long long gen = b->generation;

@@ -12,8 +12,15 @@ constexpr double HALF_LOG_2PI = 0.91893853320467274178;
 // evaluates it (negative-binomial counts).
 __device__ __forceinline__ void lgamma_digamma_pos(double x, double& lg, double& dg) {
     // p = x (x + 1) ... (x + k - 1) and its derivative dp: sum of 1 / (x + i) = dp / p, one division for the lot
+    // (x > 0 needs at most ten steps; anything else -- zero, negative, NaN -- gives NaN and, above all, terminates:
+    // for x <= -2^53, x + 1 == x)
+    if (!(x > 0.0)) {
+        lg = dg = __builtin_nan("");
+        return;
+    }
     double p = 1.0, dp = 0.0;
-    while (x < 10.0) {
+#pragma unroll 1
+    for (int it = 0; it < 10 && x < 10.0; ++it) {
         dp = fma(dp, x, p);
         p *= x;
         x += 1.0;
@@ -129,6 +136,12 @@ __device__ __forceinline__ ObsTerm obs_term_rt(int family, double y, double f, d
 // per-lattice constants of a family: see obs_term
 __device__ __forceinline__ void obs_consts(int family, double th, double (&k)[3]) {
     k[0] = k[1] = k[2] = 0.0;
+    // Stan Math rejects a scale / precision that is not positive and finite; here the lattice's density becomes NaN
+    // (the host entry point and the Python shim reject before launching)
+    if (family != GPT_OBS_POISSON_LOG && !(th > 0.0 && th < INFINITY)) {
+        k[0] = k[1] = k[2] = __builtin_nan("");
+        return;
+    }
     if (family == GPT_OBS_NORMAL) {
         k[0] = 1.0 / th;
         k[1] = log(th);

@@ -30,24 +30,21 @@ template <typename F> hipError_t sub_by_size(int n, F f) {
 #ifndef GPT_SUB_DEFAULT
 #define GPT_SUB_DEFAULT 2
 #endif
-// Radix of the step across rows: GPT_SUBLINE=0 keeps the whole-column kernels, 2 / 4 pick a variant (A/B timing).
+// Radix of the step across rows: GPT_SUBLINE=0 keeps the whole-column kernels (A/B timing; both are parity-tested).
 int sub_choice() {
     static const int r = [] {
         const char* e = getenv("GPT_SUBLINE");
         if (!e) return GPT_SUB_DEFAULT;
-        return e[0] == '0' ? 0 : (e[0] == '4' ? 4 : 2);
+        return e[0] == '0' ? 0 : 2;
     }();
     return r;
 }
 } // namespace
 
-// Sub-line variant (gpt_pow2_sub.h): fused value + gradient ops on whole lattices whose rows fit the
-// two-halves row kernels and whose columns split into four sub-lines of 256..2048 points.
+// Sub-line variant (gpt_pow2_sub.h): whole lattices whose columns split into two sub-lines of 256..4096 points.
 int gpt_pow2_sub_radix(int op, int H, int W) {
     const int r = sub_choice();
     if (r == 0 || op < 0 || op >= OP_COUNT || !gpt_pow2_supported(H, W)) return 0;
-    if (r == 4 && op_is_lpdf_vjp(op) && (W == 1024 || W == 2048 || W == 4096) && H >= 1024 && H <= 8192)
-        return 4; // experiment: fused value + gradient only
     return (H >= 512 && H <= 8192) ? 2 : 0; // sub-lines of 256..4096 points, any row length, every op
 }
 static int sub_col_blocks(int R, int H, int W, int cus) {
@@ -107,8 +104,6 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
     if (pass == 0) {
         if (!op_has_fwd(op)) return hipSuccess;
         const int in_mode = op == OP_RFFT2 ? 0 : (op == OP_INV_VJP ? 2 : 1);
-        if (R == 4)
-            return sub_by_size(a.W, [&](auto l) { return decltype(l)::row_fwd4(a, in_mode, ws, wstride, (edge_flags & 1) ? edge : nullptr, st); });
         return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, in_mode, ws, wstride, (edge_flags & 1) ? edge : nullptr, R == 2, st); });
     }
     if (pass == 1) {
@@ -143,8 +138,6 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
         if (op == OP_INV_RFFT2) alpha = 1.0 / n;
         else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
         else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
-        if (R == 4)
-            return sub_by_size(a.W, [&](auto l) { return decltype(l)::row_inv4(a, alpha, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, st); });
         return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, R == 2, st); });
     }
     return hipErrorInvalidValue;

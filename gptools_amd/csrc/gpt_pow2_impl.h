@@ -30,9 +30,6 @@
 #ifndef GPT_TRACE
 #define GPT_TRACE 0
 #endif
-#ifndef GPT_PF_COV
-#define GPT_PF_COV 0
-#endif
 #if GPT_TRACE
 // debug builds only (scripts/trace_col.py): phase timestamps (100 MHz clock) of wave 0 of every column workgroup
 __device__ unsigned long long g_col_trace[1024 * 8 * 8];
@@ -71,12 +68,6 @@ constexpr int E = GPT_E; // elements of a register tile (= the largest butterfly
 #endif
 #ifndef GPT_COL_THREADS
 #define GPT_COL_THREADS 512
-#endif
-
-// Timing-only ablation builds (make ABLATE=<bits>): 1 = no butterflies, 2 = no LDS exchanges,
-// 4 = no elementwise stage. Results are wrong by construction; never shipped.
-#ifndef GPT_ABLATE
-#define GPT_ABLATE 0
 #endif
 
 // LDS address swizzle of a line (index in doubles). Mode 0: XOR the low four bits with the next four. The
@@ -234,7 +225,6 @@ template <int N> __device__ __forceinline__ void tw_load(cplx* w, const cplx* __
 template <int N, int R, int NS, bool INV>
 __device__ __forceinline__ void stage_bfly(cplx (&v)[E], const cplx* w1) {
     constexpr int U = E / R;
-    if (GPT_ABLATE & 1) return;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         cplx x[R];
@@ -288,7 +278,6 @@ template <int T, int SWZ> __device__ __forceinline__ int rd_addr(int rb, int t, 
 template <int N, int R, int NS, int V, int SWZ>
 __device__ __forceinline__ void exchange(cplx (&v)[V][E], const int (&t)[V], double* lds) {
     constexpr int T = N / E, U = E / R;
-    if (GPT_ABLATE & 2) return;
     int o0[V][U];
 #pragma unroll
     for (int k = 0; k < V; ++k)
@@ -437,20 +426,6 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
             v[m].y -= l1[t + T * m];
         }
     }
-    // Touch the cov rows of this line (one dword per 128-byte line): the column pass reads cov in narrow column
-    // tiles right when it needs the values, cold from HBM that is 30 us on its critical path; touched here, in a
-    // streaming kernel, the lines wait for it in the Infinity Cache.
-    int pf0 = 0, pf1 = 0;
-    const bool pf = GPT_PF_COV && SUB2 && edge && a.cov;
-    if (pf) {
-        const int wfb = (W / 2 + 1) * 8;
-        const char* cp = reinterpret_cast<const char*>(a.cov + b * a.cov_bs);
-        const int off = (int)threadIdx.x % T * 128;
-        if (off < wfb) {
-            pf0 = *reinterpret_cast<const int*>(cp + (int64_t)ra * wfb + off);
-            pf1 = *reinterpret_cast<const int*>(cp + (int64_t)rb * wfb + off);
-        }
-    }
     fft_regs<W, false>(v, t, lds, wpre);
     // split the two rows: need Z[j] (own registers) and Z[W - j] (through LDS, re then im)
     cplx zc[E / 2];
@@ -509,7 +484,6 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
             rows_st<NTS>(&s1[j], zb);
         }
     }
-    if (pf) asm volatile("" ::"v"(pf0), "v"(pf1)); // keeps the touches; they have long arrived
 }
 
 // pass C --------------------------------------------------------------------------------------------
@@ -876,7 +850,7 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
             }
             __syncthreads();
         }
-        if (!(own0 && c == 0) && !(GPT_ABLATE & 4)) {
+        if (!(own0 && c == 0)) {
             // one register tile at a time: its 16 cov values are requested together, then consumed
 #pragma unroll
             for (int k = 0; k < V; ++k) {

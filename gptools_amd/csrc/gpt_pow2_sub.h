@@ -22,44 +22,12 @@
 
 namespace pow2 {
 
-#ifndef GPT_LOAD_PRED
-#define GPT_LOAD_PRED 0
-#endif
-#ifndef GPT_TW_RELOAD
-#define GPT_TW_RELOAD 0
-#endif
-#ifndef GPT_CVN
-#define GPT_CVN 0
-#endif
 #ifndef GPT_SUB_WPS2
 #define GPT_SUB_WPS2 2
 #endif
 #ifndef GPT_SUB_WPS1
 #define GPT_SUB_WPS1 4
 #endif
-#ifndef GPT_PRIO
-#define GPT_PRIO 0
-#endif
-#ifndef GPT_TOUCH
-#define GPT_TOUCH 0
-#endif
-#ifndef GPT_STAGGER
-#define GPT_STAGGER 0
-#endif
-#ifndef GPT_COV_ALL
-#define GPT_COV_ALL 0
-#endif
-#ifndef GPT_EXP_DW
-#define GPT_EXP_DW 1
-#endif
-#ifndef GPT_EXP
-#define GPT_EXP 0
-#endif
-#ifndef GPT_SUB_NOROLE
-#define GPT_SUB_NOROLE 0
-#endif
-constexpr int SUB_R = 4; // rows a pass-A'/C' workgroup combines (radix of the step across rows)
-
 template <int HS, int V_, int THREADS_> struct GeoS {
     static constexpr int T = HS / E;
     static constexpr int V = V_;
@@ -191,18 +159,13 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
     constexpr int T = G::T, TC = G::TC, TP = G::TP;
     constexpr int NPRE = tw_npre<HS>();
     constexpr bool NEEDS_COV = (OP != OP_RFFT2 && OP != OP_INV_RFFT2 && !op_is_kvjp(OP)); // cov is LOADED
-    // timing-only experiments (GPT_EXP bits; results wrong): 1 = no d/dcov stores, 2 = no cov loads, 4 = cov and
-    // d/dcov rows addressed with an aligned stride (Wf - 1), 8 = cov read from 64 rows only (cache hits)
-    constexpr int EWOP = (GPT_EXP & 1) && OP == OP_LPDF_VJP ? (int)OP_LPDF_VJP_NOCOV : OP;
-    constexpr int CVN = GPT_CVN ? GPT_CVN : (V == 1 ? 8 : E); // cov values requested together (register budget of the 128-VGPR build)
+    constexpr int CVN = V == 1 ? 8 : E; // cov values requested together (register budget of the 128-VGPR build)
     const int c = threadIdx.x % TC, tp = threadIdx.x / TC;
     double* lds = reinterpret_cast<double*>(smem) + (size_t)c * (HS + G::SKEW);
     double* red = reinterpret_cast<double*>(smem);
     const int64_t b = blockIdx.y;
     const int H = a.H;
     const ZLayout L = make_layout(a);
-    ZLayout LE = L;
-    if (GPT_EXP & 4) LE.Wf -= GPT_EXP_DW;
     EwPtrs P = make_ptrs(a, b);
     if (edge) {
         if (edge_flags & 1) P.edge_cov = edge + b * 4 * (int64_t)H;
@@ -211,15 +174,7 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
     cplx* wsb = ws + (int64_t)b * H * wstride;
     EwAcc acc;
     acc_init(acc);
-#if GPT_STAGGER
-    // Workgroups that share a CU (the second half of the grid lands on the CUs of the first) would otherwise march
-    // in phase: the late starters wait a fraction of a tile time so that one computes while the other loads.
-    if (2 * blockIdx.x >= gridDim.x) {
-#pragma unroll 1
-        for (int i = 0; i < GPT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-    if (!GPT_SUB_NOROLE && a.col0 == 0 && (int)blockIdx.x <= R / 2) {
+    if (a.col0 == 0 && (int)blockIdx.x <= R / 2) {
         col0_role<HS, THREADS, OP>(a, L, P, R, (int)blockIdx.x, wsb, wstride, tws, smem, acc);
         acc_fold(acc);
     }
@@ -258,18 +213,12 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
 #pragma unroll
         for (int k = 0; k < V; ++k) tw_load<HS>(wl[k], tws, tl[k]);
         cplx v[V][E];
-#if GPT_PRIO
-        // The two workgroups of a CU do not get equal shares (the older waves win the arbitration: the first half
-        // of the grid ends 25 us before the second): they take turns at the higher wave priority, tile by tile.
-        if ((r + (2 * blockIdx.x >= gridDim.x ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(GPT_PRIO);
-        else __builtin_amdgcn_s_setprio(0);
-#endif
         TRACE_MARK(r, 0);
 #pragma unroll
         for (int k = 0; k < V; ++k)
 #pragma unroll
             for (int m = 0; m < E; ++m) // (the lanes of the packed column 0 load it too: no per-load predicate)
-                v[k][m] = (op_has_fwd(OP) && !(GPT_LOAD_PRED && skip))
+                v[k][m] = op_has_fwd(OP)
                               ? ws_ld<NT>(&wsb[(unsigned)(rowq + tl[k]) * (unsigned)wstride + (unsigned)jl +
                                            (unsigned)(T * m) * (unsigned)wstride])
                               : make_double2(0.0, 0.0);
@@ -278,71 +227,22 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TRACE_MARK(r, 2); // ... and arrived
 #endif
-        // GPT_COV_ALL = 2: the cov values of the tile are requested right behind the spectrum loads and arrive,
-        // cold from HBM, while the forward transform runs (1: all at once, but after the transform)
-        double cve[GPT_COV_ALL == 2 ? V : 1][GPT_COV_ALL == 2 ? E : 1];
-        if (GPT_COV_ALL == 2 && NEEDS_COV && !skip) {
-#pragma unroll
-            for (int k = 0; k < V; ++k)
-#pragma unroll
-                for (int m = 0; m < E; ++m)
-                    cve[k][m] = P.cov[(unsigned)(R * (tl[k] + T * m) + q) * (unsigned)L.Wf + (unsigned)jp];
-        }
-#if GPT_TOUCH
-        // One dword of every cov row piece of the tile, requested behind the spectrum loads: the lines travel from
-        // HBM while the forward transform runs and the elementwise stage finds them on-die.
-        constexpr int NT = HS / THREADS;
-        int touch[NT];
-        if (NEEDS_COV) {
-#pragma unroll
-            for (int u = 0; u < NT; ++u)
-                touch[u] = *reinterpret_cast<const int*>(
-                    P.cov + (unsigned)(R * ((int)threadIdx.x + THREADS * u) + q) * (unsigned)L.Wf + (unsigned)(a.col0 + j0));
-        }
-#endif
         if (op_has_fwd(OP)) fft_regs<HS, false, V, 0>(v, tl, lds, wl);
-#if GPT_TOUCH
-        if (NEEDS_COV) {
-#pragma unroll
-            for (int u = 0; u < NT; ++u) asm volatile("" ::"v"(touch[u]));
-        }
-#endif
         TRACE_MARK(r, 3); // forward transform done
-        if (!skip && !(GPT_ABLATE & 4)) {
-            if (GPT_COV_ALL) {
-                double cv[V][E];
-#pragma unroll
-                for (int k = 0; k < V; ++k)
-#pragma unroll
-                    for (int m = 0; m < E; ++m) {
-                        if (GPT_COV_ALL == 2)
-                            cv[k][m] = NEEDS_COV ? cve[k][m] : 1.0;
-                        else
-                            cv[k][m] = NEEDS_COV ? P.cov[(unsigned)(R * (tl[k] + T * m) + q) * (unsigned)L.Wf + (unsigned)jp] : 1.0;
-                    }
-                SCHED_FENCE();
-#pragma unroll
-                for (int k = 0; k < V; ++k)
-#pragma unroll
-                    for (int m = 0; m < E; ++m) {
-                        v[k][m] = ew_interior_c<EWOP>(a, L, P, R * (tl[k] + T * m) + q, jp, v[k][m], cv[k][m], acc);
-                        if ((m & 3) == 3) SCHED_FENCE();
-                    }
-            } else {
+        if (!skip) {
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 // offsets into cov / d/dcov: one multiplication per register tile, the rows of a tile are a uniform
                 // stride apart
-                const unsigned icb = (unsigned)(R * tl[k] + q) * (unsigned)LE.Wf + (unsigned)jp;
-                const unsigned icstep = (unsigned)(R * T) * (unsigned)LE.Wf;
+                const unsigned icb = (unsigned)(R * tl[k] + q) * (unsigned)L.Wf + (unsigned)jp;
+                const unsigned icstep = (unsigned)(R * T) * (unsigned)L.Wf;
 #pragma unroll
                 for (int m0 = 0; m0 < E; m0 += CVN) {
                     double cv[CVN];
 #pragma unroll
                     for (int m = 0; m < CVN; ++m) {
-                        unsigned ic = icb + (unsigned)(m0 + m) * icstep;
-                        if (GPT_EXP & 8) ic = (unsigned)((R * (tl[k] + T * (m0 + m)) + q) & 63) * (unsigned)LE.Wf + (unsigned)jp;
-                        cv[m] = (NEEDS_COV && !(GPT_EXP & 2)) ? P.cov[ic] : 1.0;
+                        const unsigned ic = icb + (unsigned)(m0 + m) * icstep;
+                        cv[m] = NEEDS_COV ? P.cov[ic] : 1.0;
                     }
 #pragma unroll
                     for (int m = 0; m < CVN; ++m) {
@@ -350,13 +250,12 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
                         // (kernel-fused op: pin the row index here, or the 32 kernel evaluations of a thread are
                         // started side by side and spill)
                         if (op_is_kvjp(OP)) asm volatile("" : "+v"(irow));
-                        v[k][m0 + m] = ew_interior_ic<EWOP>(a, LE, P, irow, jp, icb + (unsigned)(m0 + m) * icstep,
+                        v[k][m0 + m] = ew_interior_ic<OP>(a, L, P, irow, jp, icb + (unsigned)(m0 + m) * icstep,
                                                             v[k][m0 + m], cv[m], acc);
                         if ((m & 3) == 3 || op_is_kvjp(OP)) SCHED_FENCE(); // (the kernel evaluation is long)
                     }
                     SCHED_FENCE();
                 }
-            }
             }
         }
         acc_fold(acc);
@@ -366,19 +265,14 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TRACE_MARK(r, 5); // ... and its stores retired
 #endif
-        if (op_has_inv(OP) && !(GPT_ABLATE & 8)) {
+        if (op_has_inv(OP)) {
             int t_inv[V];
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 t_inv[k] = tl[k];
                 asm volatile("" : "+v"(t_inv[k]), "+v"(v[0][0].x));
-#if GPT_TW_RELOAD
-                // the twiddle bases are fetched again (cached table) instead of living through the elementwise stage
-                tw_load<HS>(wl[k], tws, t_inv[k]);
-#else
 #pragma unroll
                 for (int i = 0; i < NPRE; ++i) asm volatile("" : "+v"(wl[k][i].x), "+v"(wl[k][i].y), "+v"(v[0][0].x));
-#endif
             }
             fft_regs<HS, true, V, 0>(v, t_inv, lds, wl);
             TRACE_MARK(r, 6); // inverse transform done
@@ -425,208 +319,6 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
     }
 }
 
-// pass A' -------------------------------------------------------------------------------------------
-// One workgroup = base row r: two halves of T = W/16 threads, half h transforms the real rows r + h HS and
-// r + (h + 2) HS as one complex line, splits them into the half spectra S_h and S_{h+2}; then the radix-4
-// step over p: a = S0 + S2, b = S0 - S2 (half 0), c = S1 + S3, d = -i (S1 - S3) (half 1); half 0 needs c,
-// half 1 needs b (one LDS hop); u0 = a + c, u2 = (a - c) w^{2r} (half 0), u1 = (b + d) w^r,
-// u3 = (b - d) w^{3r} (half 1); u_q goes to workspace row q HS + r.
-template <int W>
-__global__ void __launch_bounds__(2 * (W / E), 4)
-    row_fwd4_kernel(LatArgs a, int in_mode, cplx* __restrict__ ws, int wstride, double* __restrict__ edge) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int T = W / E;
-    const int half = threadIdx.x / T, t = threadIdx.x - half * T;
-    double* lds = reinterpret_cast<double*>(smem) + (size_t)half * W;
-    cplx* ldx = reinterpret_cast<cplx*>(smem); // [2][W/2] complex: the radix-4 hop reuses the exchange regions
-    const int64_t b = blockIdx.y;
-    const int H = a.H, HS = H / SUB_R;
-    const int r = blockIdx.x;
-    const int ra = r + half * HS, rb = ra + 2 * HS;
-    const double* src = in_mode == 2 ? a.aux + b * a.aux_bs : a.x + b * a.x_bs;
-    const double* r0 = src + (int64_t)ra * W;
-    const double* r1 = src + (int64_t)rb * W;
-    cplx wpre[tw_npre<W>()];
-    tw_load<W>(wpre, a.pw.tw, t);
-    cplx v[E];
-#pragma unroll
-    for (int m = 0; m < E; ++m)
-        v[m] = make_double2(__builtin_nontemporal_load(r0 + t + T * m), __builtin_nontemporal_load(r1 + t + T * m));
-    if (in_mode == 1 && a.loc) {
-        const double* l0 = a.loc + b * a.loc_bs + (int64_t)ra * W;
-        const double* l1 = a.loc + b * a.loc_bs + (int64_t)rb * W;
-#pragma unroll
-        for (int m = 0; m < E; ++m) {
-            v[m].x -= l0[t + T * m];
-            v[m].y -= l1[t + T * m];
-        }
-    }
-    fft_regs<W, false>(v, t, lds, wpre);
-    cplx zc[E / 2];
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m].x;
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < E / 2; ++m) {
-        const int j = t + T * m;
-        zc[m].x = lds[phys(j == 0 ? 0 : W - j)];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m].y;
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < E / 2; ++m) {
-        const int j = t + T * m;
-        zc[m].y = lds[phys(j == 0 ? 0 : W - j)];
-    }
-    if (edge && a.cov && t == 0) {
-        const double* cv = a.cov + b * a.cov_bs;
-        double* e = edge + b * 4 * (int64_t)H;
-        const int wf = W / 2 + 1;
-        e[ra] = cv[(int64_t)ra * wf];
-        e[rb] = cv[(int64_t)rb * wf];
-        e[H + ra] = cv[(int64_t)ra * wf + W / 2];
-        e[H + rb] = cv[(int64_t)rb * wf + W / 2];
-    }
-    // first radix-4 layer on the thread's own two rows
-    cplx s[E / 2], d[E / 2];
-#pragma unroll
-    for (int m = 0; m < E / 2; ++m) {
-        const int j = t + T * m;
-        const cplx z = v[m];
-        cplx za, zb;
-        if (j == 0) {
-            const cplx zn = v[E / 2];
-            za = make_double2(z.x, zn.x);
-            zb = make_double2(z.y, zn.y);
-        } else {
-            za = make_double2(0.5 * (z.x + zc[m].x), 0.5 * (z.y - zc[m].y));
-            zb = make_double2(0.5 * (z.y + zc[m].y), -0.5 * (z.x - zc[m].x));
-        }
-        s[m] = cadd(za, zb);
-        d[m] = csub(za, zb);
-        if (half) d[m] = mul_mi<false>(d[m]);
-    }
-    __syncthreads(); // the split is done reading LDS
-#pragma unroll
-    for (int m = 0; m < E / 2; ++m)
-        ldx[half * (W / 2) + m * T + t] = make_double2(half ? s[m].x : d[m].x, half ? s[m].y : d[m].y);
-    __syncthreads();
-    const int qlo = half, qhi = half + 2;
-    const cplx wlo = a.ph.tw[qlo * r], whi = a.ph.tw[qhi * r]; // uniform: w_H^{q r}, q r < H
-    cplx* slo = ws + ((int64_t)b * H + qlo * HS + r) * wstride;
-    cplx* shi = ws + ((int64_t)b * H + qhi * HS + r) * wstride;
-#pragma unroll
-    for (int m = 0; m < E / 2; ++m) {
-        const int j = t + T * m;
-        const cplx o = ldx[(1 - half) * (W / 2) + m * T + t];
-        cplx ulo, uhi;
-        if (half == 0) {
-            ulo = cadd(s[m], o);
-            uhi = csub(s[m], o);
-        } else {
-            ulo = cadd(o, d[m]);
-            uhi = csub(o, d[m]);
-        }
-        slo[j] = half ? cmul(ulo, wlo) : ulo;
-        shi[j] = cmul(uhi, whi);
-    }
-}
-
-// pass C' -------------------------------------------------------------------------------------------
-// Half 0 loads the four sub-line values at the positions j = t + T m (m < 8), half 1 at the mirror positions
-// W - j of m >= 8; each undoes the radix-4 step (y_p = sum_q i^{p q} conj(w^{q r}) v_q) and merges (y0, y2)
-// and (y1, y3) into the complex lines of the row pairs (r, r + 2 HS) and (r + HS, r + 3 HS); the halves swap
-// the eight values the other one transforms (one LDS hop), then half h runs the inverse line transform of
-// pair h and writes its two real rows.
-template <int W>
-__global__ void __launch_bounds__(2 * (W / E), 4)
-    row_inv4_kernel(LatArgs a, double alpha, const cplx* __restrict__ ws, int wstride, FinArgs fin,
-                    const double* __restrict__ edge) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int T = W / E;
-    const int half = threadIdx.x / T, t = threadIdx.x - half * T;
-    double* lds = reinterpret_cast<double*>(smem) + (size_t)half * W;
-    cplx* ldx = reinterpret_cast<cplx*>(smem);
-    const int64_t b = blockIdx.y;
-    const int H = a.H, HS = H / SUB_R;
-    const int r = blockIdx.x;
-    const cplx* s0 = ws + ((int64_t)b * H + r) * wstride;
-    const cplx w1 = cconj(a.ph.tw[r]), w2 = cconj(a.ph.tw[2 * r]), w3 = cconj(a.ph.tw[3 * r]);
-    cplx wpre[tw_npre<W>()];
-    tw_load<W>(wpre, a.pw.tw, t);
-    cplx v[E];
-    cplx snd[E / 2];
-    const unsigned qs = (unsigned)HS * (unsigned)wstride;
-#pragma unroll
-    for (int mm = 0; mm < E / 2; ++mm) {
-        // position (column of the packed spectrum) this thread combines
-        const int j = t + T * (mm + (half ? E / 2 : 0));
-        const int pos = half ? W - j : j;           // half 1: 1 .. W/2
-        const bool edgepos = half ? (pos == W / 2) : (j == 0);
-        const unsigned col = edgepos ? 0u : (unsigned)pos;
-        const cplx v0 = s0[col], v1 = cmul(s0[qs + col], w1), v2 = cmul(s0[2 * qs + col], w2),
-                   v3 = cmul(s0[3 * qs + col], w3);
-        const cplx e = cadd(v0, v2), f = csub(v0, v2), g = cadd(v1, v3), h = mul_mi<true>(csub(v1, v3));
-        const cplx y0 = cadd(e, g), y1 = cadd(f, h), y2 = csub(e, g), y3 = csub(f, h);
-        cplx mA, mB;
-        if (half == 0) {
-            if (edgepos) {
-                mA = make_double2(y0.x, y2.x);
-                mB = make_double2(y1.x, y3.x);
-            } else {
-                mA = make_double2(y0.x - y2.y, y0.y + y2.x);
-                mB = make_double2(y1.x - y3.y, y1.y + y3.x);
-            }
-            v[mm] = mA;
-            snd[mm] = mB;
-        } else {
-            if (edgepos) {
-                mA = make_double2(y0.y, y2.y);
-                mB = make_double2(y1.y, y3.y);
-            } else {
-                mA = make_double2(y0.x + y2.y, -y0.y + y2.x);
-                mB = make_double2(y1.x + y3.y, -y1.y + y3.x);
-            }
-            v[E / 2 + mm] = mB;
-            snd[mm] = mA;
-        }
-    }
-#pragma unroll
-    for (int mm = 0; mm < E / 2; ++mm) ldx[half * (W / 2) + mm * T + t] = snd[mm];
-    __syncthreads();
-#pragma unroll
-    for (int mm = 0; mm < E / 2; ++mm) {
-        const cplx o = ldx[(1 - half) * (W / 2) + mm * T + t];
-        if (half == 0) v[E / 2 + mm] = o;
-        else v[mm] = o;
-    }
-    fft_regs<W, true>(v, t, lds, wpre);
-    if (fin.partials && blockIdx.x == 0) {
-        __syncthreads();
-        finalize_block(fin, b, reinterpret_cast<double*>(smem));
-    }
-    const int ra = r + half * HS, rb = ra + 2 * HS;
-    if (edge && a.out_cov && t == 0) {
-        const double* e = edge + b * 4 * (int64_t)H + 2 * (int64_t)H;
-        const int wf = W / 2 + 1;
-        double* oc = a.out_cov + b * (int64_t)H * wf;
-        oc[(int64_t)ra * wf] = e[ra];
-        oc[(int64_t)rb * wf] = e[rb];
-        oc[(int64_t)ra * wf + W / 2] = e[H + ra];
-        oc[(int64_t)rb * wf + W / 2] = e[H + rb];
-    }
-    double* o0 = a.out + b * (int64_t)H * W + (int64_t)ra * W;
-    double* o1 = a.out + b * (int64_t)H * W + (int64_t)rb * W;
-#pragma unroll
-    for (int m = 0; m < E; ++m) {
-        __builtin_nontemporal_store(alpha * v[m].x, o0 + t + T * m);
-        __builtin_nontemporal_store(alpha * v[m].y, o1 + t + T * m);
-    }
-}
-
 // Plain complex line transform in place (unnormalised): `nlines` contiguous lines of N points. The sub-line
 // transforms of the long-row passes (gpt_long.hip).
 template <int N, bool INV>
@@ -652,9 +344,6 @@ __global__ void __launch_bounds__(Geo<N>::ROW_THREADS) line_fft_kernel(cplx* __r
 
 // Host-side launchers, one specialisation per line length (gpt_sub_n.hip).
 template <int N> struct LaunchSub {
-    static hipError_t row_fwd4(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, hipStream_t st);
-    static hipError_t row_inv4(const LatArgs& a, double alpha, const cplx* ws, int wstride, const FinArgs& fin,
-                               const double* edge, hipStream_t st);
     // N = HS, the sub-line length
     static hipError_t colsub(int op, const LatArgs& a, int R, cplx* ws, int wstride, const cplx* tws, double* partials,
                              int nwg, double* edge, int edge_flags, hipStream_t st);

@@ -11,6 +11,7 @@
 //   cols   Stockham line FFTs of length H down the NC packed columns
 //   ew     op-specific elementwise stage (gpt_common.h), wave/workgroup reduction for the log density
 //   cols^-1, merge row pairs, rows^-1, store
+#include <atomic>
 #include <cstdlib>
 
 #include "gpt_common.h"
@@ -171,12 +172,18 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
 
 template <int OP>
 hipError_t launch_small_t(const LatArgs& a, int cap, int sS, int nthreads, size_t lds, hipStream_t st) {
-    static bool attr_set = false; // per-process, per-instantiation: raising the cap twice is harmless
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_lattice_kernel<OP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // The attribute belongs to (kernel, device): one bit per device, set from any thread (raising the cap twice is
+    // harmless, so a lost race costs one extra call).
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = dev < 64 ? (uint64_t)1 << dev : 0;
+    if (lds > 64 * 1024 && !(attr_set.load(std::memory_order_relaxed) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_lattice_kernel<OP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(small_lattice_kernel<OP>, dim3((unsigned)a.batch), dim3(nthreads), lds, st, a, cap, sS);
     return hipGetLastError();

@@ -1,5 +1,5 @@
 // Sub-line kernels (gpt_pow2_sub.h), one translation unit per line length: compiled with -DGPT_N=<power of two>.
-// GPT_N is the ROW length of row_fwd4 / row_inv4 and the SUB-LINE length of colsub.
+// GPT_N is the SUB-LINE length of colsub (and the line length of line_fft).
 #include "gpt_pow2_sub.h"
 
 #ifndef GPT_N
@@ -29,42 +29,6 @@ constexpr int SUB_THREADS = GPT_N >= 4096 ? 512 : (GPT_N == 2048 ? GPT_SUB_T2048
 constexpr int SUB_WGS_PER_CU = GPT_SUB_WGS_PER_CU; // workgroups the register / LDS budget lets share a CU
 using GS = GeoS<GPT_N, SUB_V, SUB_THREADS>;
 } // namespace
-
-#if GPT_N >= 1024 && GPT_N <= 4096
-template <>
-hipError_t LaunchSub<GPT_N>::row_fwd4(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge,
-                                      hipStream_t st) {
-    constexpr int W = GPT_N;
-    const size_t lds = 2 * (size_t)W * sizeof(double);
-    hipError_t e = raise_lds_sub(row_fwd4_kernel<W>, lds);
-    if (e != hipSuccess) return e;
-    dim3 grid((unsigned)(a.H / SUB_R), (unsigned)a.batch);
-    hipLaunchKernelGGL(row_fwd4_kernel<W>, grid, dim3(2 * (W / E)), lds, st, a, in_mode, ws, wstride, edge);
-    return hipGetLastError();
-}
-
-template <>
-hipError_t LaunchSub<GPT_N>::row_inv4(const LatArgs& a, double alpha, const cplx* ws, int wstride, const FinArgs& fin,
-                                      const double* edge, hipStream_t st) {
-    constexpr int W = GPT_N;
-    const size_t lds = 2 * (size_t)W * sizeof(double);
-    hipError_t e = raise_lds_sub(row_inv4_kernel<W>, lds);
-    if (e != hipSuccess) return e;
-    dim3 grid((unsigned)(a.H / SUB_R), (unsigned)a.batch);
-    hipLaunchKernelGGL(row_inv4_kernel<W>, grid, dim3(2 * (W / E)), lds, st, a, alpha, ws, wstride, fin, edge);
-    return hipGetLastError();
-}
-#else
-template <>
-hipError_t LaunchSub<GPT_N>::row_fwd4(const LatArgs&, int, cplx*, int, double*, hipStream_t) {
-    return hipErrorInvalidValue;
-}
-template <>
-hipError_t LaunchSub<GPT_N>::row_inv4(const LatArgs&, double, const cplx*, int, const FinArgs&, const double*,
-                                      hipStream_t) {
-    return hipErrorInvalidValue;
-}
-#endif
 
 template <>
 hipError_t LaunchSub<GPT_N>::line_fft(bool inverse, cplx* data, int64_t nlines, const cplx* tw, hipStream_t st) {

@@ -14,14 +14,14 @@ from __future__ import annotations
 import ctypes
 import math
 import threading
+import weakref
 
 import numpy as np
 import torch
 
 from . import _lib
 
-_contexts = {}
-_lock = threading.Lock()
+_tls = threading.local()  # .contexts: device index -> Context, one set per thread, freed when the thread ends
 
 
 class NotPositiveDefinite(ValueError):
@@ -43,6 +43,15 @@ class Context:
         if rc != 0:
             raise RuntimeError(f"gpt_create failed with status {rc}")
         self.handle = h
+        # the context owns device memory (workspace, twiddles, staging): give it back when the Context object goes
+        # (its thread ended, or close() was called)
+        self._finalizer = weakref.finalize(self, self.lib.gpt_destroy, h)
+        self._finalizer.atexit = False  # at interpreter exit the process teardown frees everything
+
+    def close(self):
+        """Free the library context (workspace and tables on the device) now; the object must not be used afterwards."""
+        self._finalizer()
+        self.handle = None
 
     def sync_stream(self):
         with torch.cuda.device(self.device):
@@ -72,12 +81,21 @@ def get_context(device=None) -> Context:
         device = torch.cuda.current_device()
     if isinstance(device, torch.device):
         device = device.index if device.index is not None else torch.cuda.current_device()
-    key = (device, threading.get_ident())
-    with _lock:
-        ctx = _contexts.get(key)
-        if ctx is None:
-            ctx = _contexts[key] = Context(device)
+    table = getattr(_tls, "contexts", None)
+    if table is None:
+        table = _tls.contexts = {}
+    ctx = table.get(device)
+    if ctx is None or ctx.handle is None:
+        ctx = table[device] = Context(device)
     return ctx
+
+
+def close_contexts():
+    """Free this thread's library contexts (device workspaces); later calls create new ones."""
+    for ctx in getattr(_tls, "contexts", {}).values():
+        if ctx.handle is not None:
+            ctx.close()
+    _tls.contexts = {}
 
 
 def path_for_shape(height: int, width: int) -> int:
@@ -134,6 +152,13 @@ def _prep(main, loc, cov, dim1):
     """Normalise (main, loc, cov) to batched contiguous device tensors; returns a dict of geometry."""
     main = _dev(main)
     core = 1 if dim1 else 2
+    # batch dimensions broadcast like the reference's NumPy mirror (fft2.py: `(..., H, W)` arrays): loc / cov with MORE
+    # batch dimensions than the lattice argument expand it
+    others = [torch.Size(t.shape[:-core]) for t in (loc, cov) if hasattr(t, "shape") and len(t.shape) > core]
+    if others:
+        full = torch.broadcast_shapes(torch.Size(main.shape[:-core]), *others)
+        if tuple(full) != tuple(main.shape[:-core]):
+            main = main.expand(*full, *main.shape[-core:])
     main, bshape, m_bs = _batched(main, core)
     H = 1 if dim1 else main.shape[-2]
     W = main.shape[-1]
@@ -447,6 +472,9 @@ def _obs_lpdf_vjp(family, z, loc, cov, obs, theta, prior, dim1, check, need_cov_
         if theta is None:
             raise ValueError(f"the {family} family needs theta")
         th = _dev(theta, g["main"]).expand(g["bshape"]).contiguous()
+        # Stan Math rejects these (normal_lpdf "Scale parameter", neg_binomial_2_log_lpmf "Precision parameter")
+        if not bool(((th > 0) & torch.isfinite(th)).all()):
+            raise ValueError(("Scale" if fam == 0 else "Precision") + " parameter must be positive finite")
     lp, mn, gls = _new(g), _new(g), _new(g)
     gth = _new(g) if th is not None else None
     f = torch.empty_like(g["main"]) if need_f else None

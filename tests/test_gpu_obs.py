@@ -194,6 +194,34 @@ def test_obs_rejects_bad_arguments(fft):
         fft.gp_inv_rfft2_obs_lpdf_vjp("normal", z, None, cov, np.zeros((4, 6)))  # no theta
 
 
+@pytest.mark.parametrize("theta", [0.0, -3.5, -1e300, float("-inf"), float("nan"), float("inf")])
+@pytest.mark.parametrize("family", ["normal", "neg_binomial_2_log"])
+def test_obs_invalid_theta_terminates(fft, family, theta):
+    """A scale / precision that is not positive and finite (Stan Math rejects it): the shim raises, and the device entry
+    point -- which cannot raise -- returns NaN for that lattice instead of looping in the lgamma recurrence."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    H, W = 35, 60
+    z = rng.normal(size=(2, H, W))
+    cov = o.gp_periodic_matern_cov_rfft2(1.5, H, W, 0.9, np.array([2.0, 3.0]), np.array([H, W])) + 1e-3
+    obs = rng.poisson(40.0, size=(25, 50)).astype(float)  # counts above 32: the Stirling route of the precision terms
+    with pytest.raises(ValueError, match="parameter must be positive finite"):
+        fft.gp_inv_rfft2_obs_lpdf_vjp(family, z, None, cov, obs, np.array([1.0, theta]))
+    dev = torch.device("cuda:0")
+    zt, ct, ot = (torch.as_tensor(a, device=dev) for a in (z, cov, obs))
+    th = torch.tensor([1.0, theta], dtype=torch.float64, device=dev)
+    lp = torch.zeros(2, dtype=torch.float64, device=dev)
+    gz = torch.empty_like(zt)
+    gth = torch.zeros(2, dtype=torch.float64, device=dev)
+    fft.get_context(dev).call("gpt_gp_inv_rfft2_obs_lpdf_vjp", FAMILIES[family], zt.data_ptr(), H * W, None, 0,
+                              ct.data_ptr(), 0, ot.data_ptr(), 0, 25, 50, th.data_ptr(), 1, H, W, 2, 0, lp.data_ptr(),
+                              None, gz.data_ptr(), None, None, None, gth.data_ptr(), None)
+    torch.cuda.synchronize()
+    lp = lp.cpu().numpy()
+    assert np.isfinite(lp[0]) and np.isnan(lp[1])
+
+
 @pytest.mark.parametrize("layout", ["row", "col"])
 def test_obs_host_entry_point(fft, layout):
     """gpt_gp_inv_rfft2_obs_lpdf_host: host pointers in the caller's layout (column-major = Stan / Eigen), scalar or
