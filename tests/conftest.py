@@ -21,7 +21,7 @@ def load_golden(name):
         return {k: f[k] for k in f.files}
 
 
-SIZES_1D = [4, 5, 7, 8, 9, 10, 21, 22, 100, 128, 134, 144, 176]
+SIZES_1D = [4, 5, 7, 8, 9, 10, 21, 22, 100, 128, 134, 144, 160, 176, 192]
 SHAPES_2D = [(4, 6), (4, 7), (5, 6), (5, 7), (5, 8), (6, 7), (6, 8), (7, 9), (8, 10), (35, 60),
              (64, 64), (2, 2), (3, 2), (2, 3), (16, 12), (12, 16), (27, 25), (1, 8), (1, 7)]
 KERNEL_NAMES = ["expquad", "matern32", "matern52"]

@@ -31,7 +31,7 @@ from gptools.util import coordgrid, fft, kernels  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
-SIZES_1D = [4, 5, 7, 8, 9, 10, 21, 22, 100, 128, 134, 144, 176]
+SIZES_1D = [4, 5, 7, 8, 9, 10, 21, 22, 100, 128, 134, 144, 160, 176, 192]
 SHAPES_2D = [(4, 6), (4, 7), (5, 6), (5, 7), (5, 8), (6, 7), (6, 8), (7, 9), (8, 10), (35, 60),
              (64, 64), (2, 2), (3, 2), (2, 3), (16, 12), (12, 16), (27, 25), (1, 8), (1, 7)]
 
