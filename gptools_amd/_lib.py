@@ -33,6 +33,8 @@ _SIGNATURES = {
     "gpt_gp_rfft2_lpdf": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_ptr, c_ptr],
     "gpt_gp_rfft2_lpdf_vjp": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_ptr,
                               c_ptr, c_ptr, c_ptr],
+    "gpt_gp_rfft2_lpdf_vjp_noalloc": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_ptr,
+                                      c_ptr, c_ptr, c_ptr],
     "gpt_gp_inv_rfft2_vjp": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_ptr, c_ptr],
     "gpt_gp_rfft2_vjp": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int,
                          c_ptr, c_ptr],

@@ -40,7 +40,24 @@ struct gpt_ctx {
     };
     std::vector<ProfRec> prof;
     int total_cus = 0;
+    unsigned char* scratch = nullptr; // this device's copy of the built-in scratch array (gpt_gp_rfft2_lpdf_vjp_noalloc)
 };
+
+// Built-in scratch of the allocation-free entry point (gpt_gp_rfft2_lpdf_vjp_noalloc): twiddle tables, per-workgroup
+// partials and the packed-spectrum workspace of the lattices of one unit. Every GPU the library runs on holds its own
+// copy at its own address until the process ends. In host code the name below is only a handle for
+// hipGetSymbolAddress (gpt_create); kernels and copies get the per-device address kept in gpt_ctx::scratch.
+#define GPT_NOALLOC_SCRATCH_BYTES ((size_t)40 << 20)
+static __device__ __align__(256) unsigned char scratch[GPT_NOALLOC_SCRATCH_BYTES];
+
+// w_n^m = exp(-2 pi i m / n), m = 0 .. n-1, generated on the device (sincospi is exact at the octants)
+static __global__ void noalloc_twiddle_kernel(cplx* __restrict__ tw, int n) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    double sn, cs;
+    sincospi(2.0 * (double)m / (double)n, &sn, &cs);
+    tw[m] = make_double2(cs, -sn);
+}
 
 namespace {
 
@@ -100,9 +117,11 @@ int get_twiddles(gpt_ctx* c, int n, const cplx** out) {
     return GPT_OK;
 }
 
-int make_plan(gpt_ctx* c, int n, LinePlan& p) {
+// Stockham radices of a line of n points (host arithmetic only)
+int plan_radices(gpt_ctx* c, int n, LinePlan& p) {
     p.n = n;
     p.ns = 0;
+    p.tw = nullptr;
     int m = n;
     auto push = [&](int r) {
         if (p.ns < GPT_MAX_STAGES) p.r[p.ns] = r;
@@ -114,7 +133,12 @@ int make_plan(gpt_ctx* c, int n, LinePlan& p) {
         while (m % f == 0) { push(f); m /= f; }
     if (m > 1) push(m);
     if (p.ns > GPT_MAX_STAGES) return fail(c, GPT_ERR_UNSUPPORTED, "too many FFT stages");
-    return get_twiddles(c, n, &p.tw);
+    return GPT_OK;
+}
+
+int make_plan(gpt_ctx* c, int n, LinePlan& p) {
+    const int rc = plan_radices(c, n, p);
+    return rc != GPT_OK ? rc : get_twiddles(c, n, &p.tw);
 }
 
 int path_for_shape(int64_t H, int64_t W) {
@@ -131,6 +155,48 @@ int check_shape(gpt_ctx* c, int64_t H, int64_t W, int64_t batch, int dim1) {
     if (dim1 && H != 1) return fail(c, GPT_ERR_SHAPE, "1-D functions take height == 1");
     // n = height * width is a 32-bit Stan int in the reference (fft2.stan:15)
     if (H * W > 2147483647LL) return fail(c, GPT_ERR_SHAPE, "height * width exceeds the reference's 32-bit int");
+    return GPT_OK;
+}
+
+// The three passes over `a.batch` lattices in units of `chunk` lattices that share the workspace `ws` (chunk times
+// the path's per-lattice workspace) and `partials`, one unit after the other on the context's stream.
+int run_units(gpt_ctx* c, int op, const LatArgs& a, int path, int64_t chunk, cplx* ws, double* partials, bool may_profile) {
+    const int64_t hw = (int64_t)a.H * a.W, hwf = (int64_t)a.H * (a.W / 2 + 1);
+    for (int64_t b0 = 0; b0 < a.batch; b0 += chunk) {
+        LatArgs s = a;
+        s.batch = (a.batch - b0 < chunk) ? a.batch - b0 : chunk;
+        if (s.x) s.x += b0 * a.x_bs;
+        if (s.loc) s.loc += b0 * a.loc_bs;
+        if (s.cov) s.cov += b0 * a.cov_bs;
+        if (s.aux) s.aux += b0 * a.aux_bs;
+        if (s.cin) s.cin += b0 * a.cin_bs;
+        if (s.out) s.out += b0 * hw;
+        if (s.out_cov) s.out_cov += b0 * hwf;
+        if (s.out_c) s.out_c += b0 * hwf;
+        if (s.out_lpdf) s.out_lpdf += b0;
+        if (s.min_eig) s.min_eig += b0;
+        if (s.kpar) s.kpar += b0 * 5;
+        if (s.ksums) s.ksums += b0 * 4;
+        if (path != 1) {
+            HIP_TRY(c, gpt_launch_generic(op, s, ws, partials, c->stream));
+            continue;
+        }
+        for (int pass = 0; pass < 3; ++pass) {
+            // each pass bracketed by timing events in profiling mode
+            const bool present = pass == 1 || (pass == 0 ? op_has_fwd(op) : op_has_inv(op));
+            gpt_ctx::ProfRec pr = {nullptr, nullptr, pass == 2 ? 3 : pass};
+            if (may_profile && c->profiling && present) {
+                HIP_TRY(c, hipEventCreate(&pr.t0));
+                HIP_TRY(c, hipEventCreate(&pr.t1));
+                HIP_TRY(c, hipEventRecord(pr.t0, c->stream));
+            }
+            HIP_TRY(c, gpt_pow2_pass(pass, op, s, ws, partials, c->total_cus, c->stream));
+            if (pr.t0) {
+                HIP_TRY(c, hipEventRecord(pr.t1, c->stream));
+                c->prof.push_back(pr);
+            }
+        }
+    }
     return GPT_OK;
 }
 
@@ -199,43 +265,7 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
     if ((rc = ensure(c, c->partials, c->partials_bytes, sizeof(double) * GPT_PART * (size_t)nblk * (size_t)chunk)) !=
         GPT_OK)
         return rc;
-    const int64_t hw = (int64_t)a.H * a.W, hwf = (int64_t)a.H * (a.W / 2 + 1);
-    for (int64_t b0 = 0; b0 < a.batch; b0 += chunk) {
-        LatArgs s = a;
-        s.batch = (a.batch - b0 < chunk) ? a.batch - b0 : chunk;
-        if (s.x) s.x += b0 * a.x_bs;
-        if (s.loc) s.loc += b0 * a.loc_bs;
-        if (s.cov) s.cov += b0 * a.cov_bs;
-        if (s.aux) s.aux += b0 * a.aux_bs;
-        if (s.cin) s.cin += b0 * a.cin_bs;
-        if (s.out) s.out += b0 * hw;
-        if (s.out_cov) s.out_cov += b0 * hwf;
-        if (s.out_c) s.out_c += b0 * hwf;
-        if (s.out_lpdf) s.out_lpdf += b0;
-        if (s.min_eig) s.min_eig += b0;
-        if (s.kpar) s.kpar += b0 * 5;
-        if (s.ksums) s.ksums += b0 * 4;
-        if (path != 1) {
-            HIP_TRY(c, gpt_launch_generic(op, s, c->ws, c->partials, c->stream));
-            continue;
-        }
-        for (int pass = 0; pass < 3; ++pass) {
-            // each pass bracketed by timing events in profiling mode
-            const bool present = pass == 1 || (pass == 0 ? op_has_fwd(op) : op_has_inv(op));
-            gpt_ctx::ProfRec pr = {nullptr, nullptr, pass == 2 ? 3 : pass};
-            if (c->profiling && present) {
-                HIP_TRY(c, hipEventCreate(&pr.t0));
-                HIP_TRY(c, hipEventCreate(&pr.t1));
-                HIP_TRY(c, hipEventRecord(pr.t0, c->stream));
-            }
-            HIP_TRY(c, gpt_pow2_pass(pass, op, s, c->ws, c->partials, c->total_cus, c->stream));
-            if (pr.t0) {
-                HIP_TRY(c, hipEventRecord(pr.t1, c->stream));
-                c->prof.push_back(pr);
-            }
-        }
-    }
-    return GPT_OK;
+    return run_units(c, op, a, path, chunk, c->ws, c->partials, true);
 }
 
 LatArgs base_args(int64_t H, int64_t W, int64_t batch, int dim1) {
@@ -378,6 +408,18 @@ int gpt_create(int device, void* stream, gpt_ctx** out) {
         return GPT_ERR_ALLOC;
     }
     c->pinned = reinterpret_cast<double*>(p);
+    // this device's copy of the built-in scratch array (`device` is current) and its CU count: nothing after this
+    // point of an allocation-free call has to ask the runtime for either
+    void* sp = nullptr;
+    if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp) {
+        (void)hipHostFree(p);
+        delete c;
+        return GPT_ERR_HIP;
+    }
+    c->scratch = reinterpret_cast<unsigned char*>(sp);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        c->total_cus = prop.multiProcessorCount;
     *out = c;
     return GPT_OK;
 }
@@ -705,6 +747,81 @@ int gpt_gp_rfft2_lpdf_vjp(gpt_ctx* c, const double* y, int64_t y_bs, const doubl
     a.out_lpdf = lpdf;
     a.min_eig = min_eig;
     return run_lattice(c, grad_cov ? OP_LPDF_VJP : OP_LPDF_VJP_NOCOV, a);
+}
+
+// gpt_gp_rfft2_lpdf_vjp for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid it):
+// same arguments, same results, but twiddles, partials and workspace live in the built-in scratch array, so the call
+// makes no hipMalloc / hipFree and uses none of the context's cached buffers. Every call on a GPU shares that GPU's
+// array: calls that overlap in time on one GPU race (serialise them on one stream). Nothing in the array has to start
+// at zero: each call regenerates its tables and every kernel writes what it later reads.
+int gpt_gp_rfft2_lpdf_vjp_noalloc(gpt_ctx* c, const double* y, int64_t y_bs, const double* loc, int64_t loc_bs,
+                                  const double* cov, int64_t cov_bs, int64_t H, int64_t W, int64_t batch, int dim1,
+                                  double* lpdf, double* grad_y, double* grad_cov, double* min_eig) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    if (!y || !cov || !lpdf || !grad_y) return fail(c, GPT_ERR_SHAPE, "y, cov, lpdf and grad_y must not be null");
+    if (!c->scratch) return fail(c, GPT_ERR_HIP, "the built-in scratch array was not resolved on this device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (batch == 0) return GPT_OK;
+    const int op = grad_cov ? OP_LPDF_VJP : OP_LPDF_VJP_NOCOV;
+    LatArgs a = base_args(H, W, batch, dim1);
+    a.x = y; a.x_bs = y_bs;
+    a.loc = loc; a.loc_bs = loc_bs;
+    a.cov = cov; a.cov_bs = cov_bs;
+    a.out = grad_y;
+    a.out_cov = grad_cov;
+    a.out_lpdf = lpdf;
+    a.min_eig = min_eig;
+    const int path = path_for_shape(H, W);
+    if (path < 0) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "no kernel for a %d x %d lattice in this build", a.H, a.W);
+        return fail(c, GPT_ERR_UNSUPPORTED, buf);
+    }
+    // carve the scratch array: tables, then partials, then the workspace
+    size_t off = 0;
+    bool fits = true;
+    auto take = [&](size_t bytes) -> unsigned char* {
+        unsigned char* p = c->scratch + off;
+        off += (bytes + 255) & ~(size_t)255;
+        if (off > GPT_NOALLOC_SCRATCH_BYTES) fits = false;
+        return p;
+    };
+    auto table = [&](int n, const cplx** out) -> int {
+        cplx* t = reinterpret_cast<cplx*>(take(sizeof(cplx) * (size_t)n));
+        if (!fits) return GPT_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(noalloc_twiddle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, t, n);
+        *out = t;
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? GPT_OK : hip_fail(c, e, "twiddle table");
+    };
+    const char* too_big = "this lattice needs more than the 40 MiB of built-in scratch of the allocation-free entry point "
+                          "(three-pass lattices up to 2048 x 2048); use gpt_gp_rfft2_lpdf_vjp";
+    if ((rc = plan_radices(c, a.W, a.pw)) != GPT_OK || (rc = plan_radices(c, a.H, a.ph)) != GPT_OK) return rc;
+    if ((rc = table(a.W, &a.pw.tw)) != GPT_OK) return fits ? rc : fail(c, GPT_ERR_UNSUPPORTED, too_big);
+    if (a.H == a.W) a.ph.tw = a.pw.tw;
+    else if ((rc = table(a.H, &a.ph.tw)) != GPT_OK) return fits ? rc : fail(c, GPT_ERR_UNSUPPORTED, too_big);
+    if (path == 0) {
+        HIP_TRY(c, gpt_launch_small(op, a, c->stream));
+        return GPT_OK;
+    }
+    if (path == 1) {
+        const int R = gpt_pow2_sub_radix(op, a.H, a.W);
+        if (R && (rc = table(a.H / R, &a.tw_sub)) != GPT_OK) return fits ? rc : fail(c, GPT_ERR_UNSUPPORTED, too_big);
+    }
+    const size_t per = path == 1 ? gpt_pow2_workspace_bytes(a.H, a.W) : gpt_generic_workspace_bytes(a.H, a.W);
+    const int nblk = path == 1 ? gpt_pow2_col_blocks(a.H, a.W, c->total_cus > 0 ? c->total_cus : 256)
+                               : gpt_generic_col_blocks(a.H, a.W);
+    if (c->total_cus == 0) c->total_cus = 256;
+    const size_t per_lattice = ((per + 255) & ~(size_t)255) + sizeof(double) * GPT_PART * (size_t)nblk;
+    const size_t left = off + 512 <= GPT_NOALLOC_SCRATCH_BYTES ? GPT_NOALLOC_SCRATCH_BYTES - off - 512 : 0;
+    int64_t chunk = (int64_t)(left / per_lattice);
+    if (chunk < 1) return fail(c, GPT_ERR_UNSUPPORTED, too_big);
+    if (chunk > batch) chunk = batch;
+    double* partials = reinterpret_cast<double*>(take(sizeof(double) * GPT_PART * (size_t)nblk * (size_t)chunk));
+    cplx* ws = reinterpret_cast<cplx*>(take(per * (size_t)chunk));
+    if (!fits) return fail(c, GPT_ERR_UNSUPPORTED, too_big);
+    return run_units(c, op, a, path, chunk, ws, partials, false);
 }
 
 // prior_lp != null: the white-noise prior of the non-centred models rides along (zbar -= z, prior_lp[b] =

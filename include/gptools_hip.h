@@ -162,6 +162,18 @@ int gpt_gp_rfft2_lpdf(gpt_ctx*, const double* y, int64_t y_bs, const double* loc
 int gpt_gp_rfft2_lpdf_vjp(gpt_ctx*, const double* y, int64_t y_bs, const double* loc, int64_t loc_bs,
                           const double* cov, int64_t cov_bs, int64_t height, int64_t width, int64_t batch,
                           int dim1, double* lpdf, double* grad_y, double* grad_cov, double* min_eig);
+/* The function above for callers that cannot allocate. No counterpart in the reference: it exists for code under HIP
+ * graph capture, tight serving loops and harnesses that forbid hipMalloc. Same arguments and results as
+ * gpt_gp_rfft2_lpdf_vjp, but twiddle tables, partial sums and the packed-spectrum workspace live in a 40 MiB
+ * `static __device__` array built into the library (one copy per GPU, held until the process ends), so the call makes
+ * no hipMalloc / hipFree and touches none of the context's cached buffers. Limit: lattices of the one-workgroup path
+ * of any batch size, three-pass lattices whose workspace fits the array (up to 2048 x 2048; larger batches are
+ * processed in units that fit); anything beyond returns GPT_ERR_UNSUPPORTED with a message. Every call on a GPU
+ * shares that GPU's array: calls that overlap in time on one GPU (two streams, two contexts, two processes are
+ * fine -- each process has its own copy -- but two threads of one process are not) race. */
+int gpt_gp_rfft2_lpdf_vjp_noalloc(gpt_ctx*, const double* y, int64_t y_bs, const double* loc, int64_t loc_bs,
+                                  const double* cov, int64_t cov_bs, int64_t height, int64_t width, int64_t batch,
+                                  int dim1, double* lpdf, double* grad_y, double* grad_cov, double* min_eig);
 /* Reverse mode of gp_inv_rfft(2): fbar[batch][H][W] -> zbar[batch][H][W], covbar[batch][H][W/2+1] (may be
  * NULL); d/dloc = fbar. */
 int gpt_gp_inv_rfft2_vjp(gpt_ctx*, const double* z, int64_t z_bs, const double* cov, int64_t cov_bs,
