@@ -1,489 +1,500 @@
-// gptools_hip.hpp -- C++ user header for cmdstan (USER_HEADER=...) that binds the Fourier-GP functions of
-// onnela-lab/gptools, declared without bodies in gptools_amd/stan/gptools/*.stan, to libgptools_hip.so.
+// gptools_hip.hpp -- C++ user header for cmdstan (USER_HEADER=...): the Stan-typed veneer that binds the Fourier-GP
+// functions of onnela-lab/gptools, declared without bodies in gptools_amd/stan/gptools/*.stan, to libgptools_hip.so.
 //
 //   stanc --allow-undefined --include-paths=<gptools_amd/stan> model.stan
 //   make  USER_HEADER=<repo>/include/gptools_hip.hpp  CXXFLAGS+=-I<repo>/include
 //         LDFLAGS+="-L<repo>/gptools_amd -Wl,-rpath,<repo>/gptools_amd" LDLIBS+=-lgptools_hip
 // (gptools_amd.stan.compile_model sets all of this).
 //
-// cmdstan includes a user header INSIDE the model's namespace, after the forward declarations stanc
-// generated for the undefined functions, so nothing here names a namespace of its own. Every function is
-// a template over its argument types (double or stan::math::var elements), takes the trailing
-// `std::ostream* pstream__` stanc adds, and `_lpdf` functions carry the leading `bool propto__`.
+// Everything that does not name a Stan type -- context, error mapping, every value and reverse-mode call sequence on
+// column-major pointers -- lives in gptools_hip_bind.hpp, which IS compiled and run by this repository's tests
+// (tests/test_gpu_bind_cpp.py). What is left here is mechanical: unwrap Stan's arguments into plain column-major
+// matrices, call one bind function, and register ONE reverse-pass callback that calls the matching `*_vjp`.
 //
-// Values come from the host-pointer C ABI (include/gptools_hip.h, GPT_COL_MAJOR: Stan matrices are Eigen
-// column-major); reverse mode registers ONE callback per call that asks the library for the vector-
-// Jacobian product (the fused gp_rfft2_lpdf + gradient kernel for the log density).
+// cmdstan includes a user header INSIDE the model's namespace, after the forward declarations stanc generated for the
+// undefined functions. A definition only binds to such a declaration if its template head is the same, so every
+// function below repeats the form stanc 2.36 emits: one type parameter per non-int argument, a trailing
+// `stan::require_all_t<...>* = nullptr` listing `stan::is_col_vector` / `stan::is_eigen_matrix_dynamic` +
+// `stan::is_vt_not_complex` / `stan::is_vt_complex` per container and `stan::is_stan_scalar` per real, a return type
+// spelled with `stan::promote_args_t<stan::base_type_t<...>>`, `const int&` for ints, the trailing
+// `std::ostream* pstream__`, and a leading `bool propto__` on `_lpdf` functions.
 //
-// STATUS: written against the Stan Math 4.x API (cmdstan 2.36, the version the reference pins in
-// .github/workflows/python.yml:19). The build image has neither stanc nor Stan Math, so this header has
-// NOT been compiled here; the C ABI underneath it is what the GPU parity tests exercise (the same entry
-// points, column-major, in tests/test_gpu_parity.py::test_host_entry_points_col_major).
+// STATUS -- EXPERIMENTAL, UNCOMPILED: the build image has neither stanc nor Stan Math (cmdstan 2.36 is what the
+// reference pins, .github/workflows/python.yml:19), so THIS file has never met a compiler and the template heads are
+// written from the stanc3 code generator's documented output, not checked against a generated .hpp. If a model fails
+// to link with "undefined reference to <function>" or "call is ambiguous", diff the forward declaration in the
+// generated <model>.hpp against the head here. All functions accept `var` arguments,
+// including the real-FFT layer and the layout helpers (linear maps: their reverse mode is the adjoint transform).
 #ifndef GPTOOLS_HIP_HPP
 #define GPTOOLS_HIP_HPP
 
-#include <gptools_hip.h>
+#include <gptools_hip_bind.hpp>
 #include <stan/math.hpp>
 
 #include <ostream>
-#include <stdexcept>
-#include <string>
 
-namespace gptools_hip_detail {
+namespace gptools_hip_stan {
+namespace b = gptools_hip;
+using stan::math::var;
+using b::cplx;
+using VecD = Eigen::Matrix<double, -1, 1>;
+using MatD = Eigen::Matrix<double, -1, -1>;
+using VecC = Eigen::Matrix<cplx, -1, 1>;
+using MatC = Eigen::Matrix<cplx, -1, -1>;
+template <typename S, int C> using Mat = Eigen::Matrix<S, -1, C>;
 
-// One library context per calling thread (cmdstan chains are processes, or threads under STAN_THREADS).
-inline gpt_ctx* ctx() {
-    struct Holder {
-        gpt_ctx* c = nullptr;
-        Holder() {
-            if (gpt_create(0, nullptr, &c) != GPT_OK) throw std::runtime_error("gptools_hip: no usable GPU");
-        }
-        ~Holder() { gpt_destroy(c); }
-    };
-    thread_local Holder h;
-    return h.c;
-}
+template <typename T> using scalar_of = stan::promote_args_t<stan::base_type_t<T>>;
+template <typename... Ts> inline constexpr bool any_var_v = stan::is_var<stan::return_type_t<Ts...>>::value;
+template <typename T> inline constexpr bool is_var_v = stan::is_var<stan::base_type_t<T>>::value;
 
-// Map the library's status codes onto what the reference's Stan code does.
-inline void check(int rc, const char* fn) {
-    if (rc == GPT_OK) return;
-    const std::string msg = std::string(fn) + ": " + gpt_last_error(ctx());
-    if (rc == GPT_ERR_NOT_PD) throw std::domain_error(gpt_last_error(ctx()));  // Stan `reject`
-    if (rc == GPT_ERR_SHAPE) throw std::invalid_argument(msg);
-    throw std::runtime_error(msg);
-}
+// plain column-major copies of the values of (possibly var, possibly expression) arguments
+template <int C, typename T> inline Mat<double, C> real_val(const T& x) { return stan::math::value_of(x); }
+template <int C, typename T> inline Mat<cplx, C> cplx_val(const T& x) { return stan::math::value_of(x); }
 
-template <typename T> using value_mat_t = Eigen::Matrix<double, T::RowsAtCompileTime, T::ColsAtCompileTime>;
-
-template <typename T> inline auto val(const T& x) { return stan::math::value_of(x).eval(); }
-
-template <typename... Ts> using any_var = stan::math::disjunction<stan::is_var<stan::scalar_type_t<Ts>>...>;
-
-inline void require_no_var(bool has_var, const char* fn) {
-    if (has_var)
-        throw std::domain_error(std::string(fn) +
-                                " is not differentiable through the HIP path; differentiate gp_rfft(2), "
-                                "gp_inv_rfft(2), gp_rfft(2)_lpdf or the spectral kernels instead");
-}
-
-}  // namespace gptools_hip_detail
-
-// ===================================================================================================
-// Real-FFT layer (stan/gptools/util.stan:255-330): values only.
-template <typename T0__>
-inline Eigen::Matrix<std::complex<double>, -1, 1> rfft(const T0__& y, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
-    d::require_no_var(d::any_var<T0__>::value, "rfft");
-    const Eigen::VectorXd yv = d::val(y);
-    Eigen::Matrix<std::complex<double>, -1, 1> out(yv.size() / 2 + 1);
-    d::check(gpt_rfft2_host(d::ctx(), GPT_COL_MAJOR, yv.data(), 1, yv.size(), reinterpret_cast<double*>(out.data())),
-             "rfft");
-    return out;
-}
-
-template <typename T0__>
-inline Eigen::Matrix<std::complex<double>, -1, 1> expand_rfft(const T0__& y, const int& n, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
-    if (y.size() != n / 2 + 1)  // util.stan:274-276
-        throw std::domain_error("expected complex vector with " + std::to_string(n / 2 + 1) + " elements but got " +
-                                std::to_string(y.size()));
-    const Eigen::Matrix<std::complex<double>, -1, 1> yv = y;
-    Eigen::Matrix<std::complex<double>, -1, 1> out(n);
-    d::check(gpt_expand_rfft_host(d::ctx(), reinterpret_cast<const double*>(yv.data()), n,
-                                  reinterpret_cast<double*>(out.data())),
-             "expand_rfft");
-    return out;
-}
-
-template <typename T0__>
-inline Eigen::VectorXd inv_rfft(const T0__& z, const int& n, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
-    const Eigen::Matrix<std::complex<double>, -1, 1> zv = z;
-    Eigen::VectorXd out(n);
-    d::check(gpt_inv_rfft2_host(d::ctx(), GPT_COL_MAJOR, reinterpret_cast<const double*>(zv.data()), 1, n, out.data()),
-             "inv_rfft");
-    return out;
-}
-
-template <typename T0__>
-inline Eigen::Matrix<std::complex<double>, -1, -1> rfft2(const T0__& y, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
-    d::require_no_var(d::any_var<T0__>::value, "rfft2");
-    const Eigen::MatrixXd yv = d::val(y);
-    Eigen::Matrix<std::complex<double>, -1, -1> out(yv.rows(), yv.cols() / 2 + 1);
-    d::check(gpt_rfft2_host(d::ctx(), GPT_COL_MAJOR, yv.data(), yv.rows(), yv.cols(),
-                            reinterpret_cast<double*>(out.data())),
-             "rfft2");
-    return out;
-}
-
-template <typename T0__>
-inline Eigen::MatrixXd inv_rfft2(const T0__& z, const int& m, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
-    const Eigen::Matrix<std::complex<double>, -1, -1> zv = z;
-    Eigen::MatrixXd out(zv.rows(), m);
-    d::check(gpt_inv_rfft2_host(d::ctx(), GPT_COL_MAJOR, reinterpret_cast<const double*>(zv.data()), zv.rows(), m,
-                                out.data()),
-             "inv_rfft2");
-    return out;
-}
-
-// ===================================================================================================
-// Layout helpers and scales (fft1.stan:14-51,108-118; fft2.stan:13-100): values only.
-#define GPTOOLS_HIP_SCALE(NAME, MAT, DIM1)                                                                       \
-    template <typename T0__> inline MAT NAME(const T0__& cov, const int& n, std::ostream* pstream__) {          \
-        namespace d = gptools_hip_detail;                                                                        \
-        d::require_no_var(d::any_var<T0__>::value, #NAME);                                                       \
-        const MAT cv = d::val(cov);                                                                              \
-        MAT out(cv.rows(), cv.cols());                                                                           \
-        d::check(gpt_gp_evaluate_rfft2_scale_host(d::ctx(), GPT_COL_MAJOR, cv.data(), DIM1 ? 1 : cv.rows(), n,   \
-                                                  DIM1, out.data()),                                             \
-                 #NAME);                                                                                         \
-        return out;                                                                                              \
+// a complex<var> container over two arena matrices of var (real and imaginary parts keep their own varis)
+template <int C> struct CplxVarOut {
+    stan::math::arena_t<Mat<var, C>> re, im;
+    explicit CplxVarOut(const Mat<cplx, C>& v) : re(v.real()), im(v.imag()) {}
+    Mat<std::complex<var>, C> result() const {
+        Mat<std::complex<var>, C> r(re.rows(), re.cols());
+        for (Eigen::Index k = 0; k < r.size(); ++k) r.coeffRef(k) = std::complex<var>(re.coeff(k), im.coeff(k));
+        return r;
     }
-GPTOOLS_HIP_SCALE(gp_evaluate_rfft_scale, Eigen::VectorXd, 1)
-GPTOOLS_HIP_SCALE(gp_evaluate_rfft2_scale, Eigen::MatrixXd, 0)
-#undef GPTOOLS_HIP_SCALE
-
-template <typename T0__>
-inline Eigen::VectorXd gp_unpack_rfft(const T0__& x, const int& n, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
-    const Eigen::Matrix<std::complex<double>, -1, 1> xv = x;
-    Eigen::VectorXd out(n);
-    d::check(gpt_gp_unpack_rfft2_host(d::ctx(), GPT_COL_MAJOR, reinterpret_cast<const double*>(xv.data()), 1, n, 1,
-                                      out.data()),
-             "gp_unpack_rfft");
-    return out;
+    Mat<cplx, C> adj() const {
+        Mat<cplx, C> a(re.rows(), re.cols());
+        for (Eigen::Index k = 0; k < a.size(); ++k) a.coeffRef(k) = cplx(re.coeff(k).adj(), im.coeff(k).adj());
+        return a;
+    }
+};
+// add a complex cotangent to a container of complex<var> held in the arena
+template <typename A, int C> inline void add_cplx_adj(A& z, const Mat<cplx, C>& g) {
+    for (Eigen::Index k = 0; k < g.size(); ++k) {
+        z.coeffRef(k).real().adj() += g.coeff(k).real();
+        z.coeffRef(k).imag().adj() += g.coeff(k).imag();
+    }
 }
 
-template <typename T0__>
-inline Eigen::MatrixXd gp_unpack_rfft2(const T0__& z, const int& m, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
-    const Eigen::Matrix<std::complex<double>, -1, -1> zv = z;
-    Eigen::MatrixXd out(zv.rows(), m);
-    d::check(gpt_gp_unpack_rfft2_host(d::ctx(), GPT_COL_MAJOR, reinterpret_cast<const double*>(zv.data()), zv.rows(),
-                                      m, 0, out.data()),
-             "gp_unpack_rfft2");
-    return out;
-}
-
-template <typename T0__>
-inline Eigen::Matrix<std::complex<double>, -1, 1> gp_pack_rfft(const T0__& z, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
-    d::require_no_var(d::any_var<T0__>::value, "gp_pack_rfft");
-    const Eigen::VectorXd zv = d::val(z);
-    Eigen::Matrix<std::complex<double>, -1, 1> out(zv.size() / 2 + 1);
-    d::check(gpt_gp_pack_rfft2_host(d::ctx(), GPT_COL_MAJOR, zv.data(), 1, zv.size(), 1,
-                                    reinterpret_cast<double*>(out.data())),
-             "gp_pack_rfft");
-    return out;
-}
-
-template <typename T0__>
-inline Eigen::Matrix<std::complex<double>, -1, -1> gp_pack_rfft2(const T0__& z, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
-    d::require_no_var(d::any_var<T0__>::value, "gp_pack_rfft2");
-    const Eigen::MatrixXd zv = d::val(z);
-    Eigen::Matrix<std::complex<double>, -1, -1> out(zv.rows(), zv.cols() / 2 + 1);
-    d::check(gpt_gp_pack_rfft2_host(d::ctx(), GPT_COL_MAJOR, zv.data(), zv.rows(), zv.cols(), 0,
-                                    reinterpret_cast<double*>(out.data())),
-             "gp_pack_rfft2");
-    return out;
-}
-
-// ===================================================================================================
-// The differentiable functions. MAT is Eigen::VectorXd (1-D, dim1 = 1, "height" 1) or Eigen::MatrixXd.
-namespace gptools_hip_detail {
-
-template <typename MAT> inline int64_t height_of(const MAT& m, int dim1) { return dim1 ? 1 : m.rows(); }
-template <typename MAT> inline int64_t width_of(const MAT& m, int dim1) { return dim1 ? m.size() : m.cols(); }
-
-// result matrix type: var elements as soon as one argument has them
-template <typename MAT, typename... Ts>
-using result_mat_t = std::conditional_t<any_var<Ts...>::value,
-                                        Eigen::Matrix<stan::math::var, MAT::RowsAtCompileTime, MAT::ColsAtCompileTime>,
-                                        MAT>;
-
-// z = gp_rfft(2)(y, loc, cov) or f = gp_inv_rfft(2)(z, loc, cov); FORWARD selects which.
-template <bool FORWARD, typename MAT, typename T0, typename T1, typename T2>
-inline result_mat_t<MAT, T0, T1, T2> transform(const T0& a0, const T1& loc, const T2& cov, int dim1, const char* fn) {
-    using stan::math::var;
-    const MAT av = val(a0), lv = val(loc), cv = val(cov);
-    const int64_t H = height_of(av, dim1), W = width_of(av, dim1);
-    if (lv.size() != av.size() || cv.size() != H * (W / 2 + 1))
-        throw std::invalid_argument(std::string(fn) + ": argument sizes do not match");
-    MAT out(av.rows(), av.cols());
-    check(FORWARD ? gpt_gp_rfft2_host(ctx(), GPT_COL_MAJOR, av.data(), lv.data(), cv.data(), H, W, dim1, out.data())
-                  : gpt_gp_inv_rfft2_host(ctx(), GPT_COL_MAJOR, av.data(), lv.data(), cv.data(), H, W, dim1, out.data()),
-          fn);
-    if constexpr (!any_var<T0, T1, T2>::value) {
+// ---- real input -> complex output (rfft, rfft2, gp_pack_rfft, gp_pack_rfft2) ---------------------------------------
+template <int C, typename T, typename Fwd, typename Vjp>
+inline Mat<std::complex<scalar_of<T>>, C> real_to_cplx(const T& x, b::Shape s, Eigen::Index orows, Eigen::Index ocols,
+                                                        Fwd fwd, Vjp vjp) {
+    const Mat<double, C> xv = real_val<C>(x);
+    Mat<cplx, C> out(orows, ocols);
+    fwd(xv.data(), s, out.data());
+    if constexpr (!is_var_v<T>) {
         return out;
     } else {
-        using stan::math::arena_t;
-        arena_t<Eigen::Matrix<var, MAT::RowsAtCompileTime, MAT::ColsAtCompileTime>> res = out;
-        auto arena_a = stan::math::to_arena(a0);
-        auto arena_l = stan::math::to_arena(loc);
-        auto arena_c = stan::math::to_arena(cov);
-        stan::math::reverse_pass_callback([res, arena_a, arena_l, arena_c, dim1, H, W, fn]() mutable {
-            const MAT bar = res.adj();
-            const MAT av2 = stan::math::value_of(arena_a), lv2 = stan::math::value_of(arena_l),
-                      cv2 = stan::math::value_of(arena_c);
-            MAT abar(av2.rows(), av2.cols()), cbar(cv2.rows(), cv2.cols());
-            if (FORWARD)  // zbar -> ybar, covbar ; locbar = -ybar
-                check(gpt_gp_rfft2_vjp_host(ctx(), GPT_COL_MAJOR, av2.data(), lv2.data(), cv2.data(), bar.data(), H, W,
-                                            dim1, abar.data(), cbar.data()),
-                      fn);
-            else  // fbar -> zbar, covbar ; locbar = fbar
-                check(gpt_gp_inv_rfft2_vjp_host(ctx(), GPT_COL_MAJOR, av2.data(), cv2.data(), bar.data(), H, W, dim1,
-                                                abar.data(), cbar.data()),
-                      fn);
-            if constexpr (!stan::is_constant<T0>::value) arena_a.adj() += abar;
-            if constexpr (!stan::is_constant<T1>::value) {
-                if (FORWARD) arena_l.adj() -= abar;
-                else arena_l.adj() += bar;
+        CplxVarOut<C> res(out);
+        auto ax = stan::math::to_arena(x);
+        stan::math::reverse_pass_callback([res, ax, s, vjp]() mutable {
+            const Mat<cplx, C> bar = res.adj();
+            Mat<double, C> xbar(ax.rows(), ax.cols());
+            vjp(bar.data(), s, xbar.data());
+            ax.adj() += xbar;
+        });
+        return res.result();
+    }
+}
+// ---- complex input -> real output (inv_rfft, inv_rfft2, gp_unpack_rfft, gp_unpack_rfft2) ---------------------------
+template <int C, typename T, typename Fwd, typename Vjp>
+inline Mat<scalar_of<T>, C> cplx_to_real(const T& z, b::Shape s, Eigen::Index orows, Eigen::Index ocols, Fwd fwd, Vjp vjp) {
+    const Mat<cplx, C> zv = cplx_val<C>(z);
+    Mat<double, C> out(orows, ocols);
+    fwd(zv.data(), s, out.data());
+    if constexpr (!is_var_v<T>) {
+        return out;
+    } else {
+        stan::math::arena_t<Mat<var, C>> res = out;
+        stan::math::arena_t<Mat<std::complex<var>, C>> az = z;
+        stan::math::reverse_pass_callback([res, az, s, vjp]() mutable {
+            const Mat<double, C> bar = res.adj();
+            Mat<cplx, C> zbar(az.rows(), az.cols());
+            vjp(bar.data(), s, zbar.data());
+            add_cplx_adj<decltype(az), C>(az, zbar);
+        });
+        return Mat<var, C>(res);
+    }
+}
+// ---- gp_evaluate_rfft_scale / gp_evaluate_rfft2_scale -------------------------------------------------------------
+template <int C, typename T> inline Mat<scalar_of<T>, C> scale(const T& cov, b::Shape s) {
+    const Mat<double, C> cv = real_val<C>(cov);
+    b::require_sizes(cv.size() == s.nf(), "gp_evaluate_rfft(2)_scale");
+    Mat<double, C> out(cv.rows(), cv.cols());
+    b::gp_evaluate_scale(cv.data(), s, out.data());
+    if constexpr (!is_var_v<T>) {
+        return out;
+    } else {
+        stan::math::arena_t<Mat<var, C>> res = out;
+        auto ac = stan::math::to_arena(cov);
+        stan::math::reverse_pass_callback([res, ac, s]() mutable {
+            const Mat<double, C> bar = res.adj(), cv2 = stan::math::value_of(ac), sc = stan::math::value_of(res);
+            Mat<double, C> cbar(cv2.rows(), cv2.cols());
+            b::gp_evaluate_scale_vjp(cv2.data(), sc.data(), bar.data(), s, cbar.data());
+            ac.adj() += cbar;
+        });
+        return Mat<var, C>(res);
+    }
+}
+// ---- gp_rfft(2) / gp_inv_rfft(2) -----------------------------------------------------------------------------------
+template <bool FORWARD, int C, typename T0, typename T1, typename T2>
+inline Mat<stan::return_type_t<T0, T1, T2>, C> transform(const T0& a0, const T1& loc, const T2& cov, int dim1, const char* fn) {
+    const Mat<double, C> av = real_val<C>(a0), lv = real_val<C>(loc), cv = real_val<C>(cov);
+    const b::Shape s{dim1 ? 1 : av.rows(), dim1 ? av.size() : av.cols(), dim1};
+    b::require_sizes(lv.size() == av.size() && cv.size() == s.nf(), fn);
+    Mat<double, C> out(av.rows(), av.cols());
+    b::gp_transform(FORWARD, av.data(), lv.data(), cv.data(), s, out.data());
+    if constexpr (!any_var_v<T0, T1, T2>) {
+        return out;
+    } else {
+        stan::math::arena_t<Mat<var, C>> res = out;
+        auto aa = stan::math::to_arena(a0);
+        auto al = stan::math::to_arena(loc);
+        auto ac = stan::math::to_arena(cov);
+        stan::math::reverse_pass_callback([res, aa, al, ac, s]() mutable {
+            const Mat<double, C> bar = res.adj(), av2 = stan::math::value_of(aa), lv2 = stan::math::value_of(al),
+                                 cv2 = stan::math::value_of(ac);
+            Mat<double, C> abar(av2.rows(), av2.cols()), cbar(cv2.rows(), cv2.cols());
+            b::gp_transform_vjp(FORWARD, av2.data(), lv2.data(), cv2.data(), bar.data(), s, abar.data(), cbar.data());
+            if constexpr (is_var_v<T0>) aa.adj() += abar;
+            if constexpr (is_var_v<T1>) {
+                if (FORWARD) al.adj() -= abar; // z depends on y - loc
+                else al.adj() += bar;          // f = ... + loc
             }
-            if constexpr (!stan::is_constant<T2>::value) arena_c.adj() += cbar;
+            if constexpr (is_var_v<T2>) ac.adj() += cbar;
         });
-        return Eigen::Matrix<var, MAT::RowsAtCompileTime, MAT::ColsAtCompileTime>(res);
+        return Mat<var, C>(res);
     }
 }
-
-template <typename MAT, typename T0, typename T1, typename T2>
+// ---- gp_rfft_lpdf / gp_rfft2_lpdf: fused value + gradient, ONE trip to the GPU per log-density evaluation -----------
+template <int C, typename T0, typename T1, typename T2>
 inline stan::return_type_t<T0, T1, T2> lpdf(const T0& y, const T1& loc, const T2& cov, int dim1, const char* fn) {
-    using stan::math::var;
-    const MAT yv = val(y), lv = val(loc), cv = val(cov);
-    const int64_t H = height_of(yv, dim1), W = width_of(yv, dim1);
-    if (lv.size() != yv.size() || cv.size() != H * (W / 2 + 1))
-        throw std::invalid_argument(std::string(fn) + ": argument sizes do not match");
-    double value = 0.0;
-    if constexpr (!any_var<T0, T1, T2>::value) {
-        check(gpt_gp_rfft2_lpdf_host(ctx(), GPT_COL_MAJOR, yv.data(), lv.data(), cv.data(), H, W, dim1, &value, nullptr,
-                                     nullptr),
-              fn);
-        return value;
+    const Mat<double, C> yv = real_val<C>(y), lv = real_val<C>(loc), cv = real_val<C>(cov);
+    const b::Shape s{dim1 ? 1 : yv.rows(), dim1 ? yv.size() : yv.cols(), dim1};
+    b::require_sizes(lv.size() == yv.size() && cv.size() == s.nf(), fn);
+    if constexpr (!any_var_v<T0, T1, T2>) {
+        return b::gp_lpdf(yv.data(), lv.data(), cv.data(), s, nullptr, nullptr);
     } else {
-        // fused value + gradient: one trip to the GPU per log-density evaluation
-        stan::math::arena_t<MAT> gy(yv.rows(), yv.cols()), gc(cv.rows(), cv.cols());
-        check(gpt_gp_rfft2_lpdf_host(ctx(), GPT_COL_MAJOR, yv.data(), lv.data(), cv.data(), H, W, dim1, &value,
-                                     gy.data(), stan::is_constant<T2>::value ? nullptr : gc.data()),
-              fn);
-        auto arena_y = stan::math::to_arena(y);
-        auto arena_l = stan::math::to_arena(loc);
-        auto arena_c = stan::math::to_arena(cov);
-        return stan::math::make_callback_var(value, [arena_y, arena_l, arena_c, gy, gc](auto& vi) mutable {
-            if constexpr (!stan::is_constant<T0>::value) arena_y.adj() += vi.adj() * gy;
-            if constexpr (!stan::is_constant<T1>::value) arena_l.adj() -= vi.adj() * gy;
-            if constexpr (!stan::is_constant<T2>::value) arena_c.adj() += vi.adj() * gc;
+        stan::math::arena_t<Mat<double, C>> gy(yv.rows(), yv.cols()), gc(cv.rows(), cv.cols());
+        const double value = b::gp_lpdf(yv.data(), lv.data(), cv.data(), s, gy.data(), is_var_v<T2> ? gc.data() : nullptr);
+        auto ay = stan::math::to_arena(y);
+        auto al = stan::math::to_arena(loc);
+        auto ac = stan::math::to_arena(cov);
+        return stan::math::make_callback_var(value, [ay, al, ac, gy, gc](auto& vi) mutable {
+            if constexpr (is_var_v<T0>) ay.adj() += vi.adj() * gy;
+            if constexpr (is_var_v<T1>) al.adj() -= vi.adj() * gy;
+            if constexpr (is_var_v<T2>) ac.adj() += vi.adj() * gc;
         });
     }
 }
-
-template <typename MAT, typename T0>
-inline stan::return_type_t<T0> ladj(const T0& cov, int width, int dim1, const char* fn) {
-    const MAT cv = val(cov);
-    const int64_t H = dim1 ? 1 : cv.rows();
-    double value = 0.0;
-    if constexpr (!any_var<T0>::value) {
-        check(gpt_gp_rfft2_log_abs_det_jac_host(ctx(), GPT_COL_MAJOR, cv.data(), H, width, dim1, &value, nullptr), fn);
-        return value;
+template <int C, typename T0> inline stan::return_type_t<T0> ladj(const T0& cov, b::Shape s) {
+    const Mat<double, C> cv = real_val<C>(cov);
+    b::require_sizes(cv.size() == s.nf(), "gp_rfft(2)_log_abs_det_jac");
+    if constexpr (!is_var_v<T0>) {
+        return b::gp_ladj(cv.data(), s, nullptr);
     } else {
-        stan::math::arena_t<MAT> gc(cv.rows(), cv.cols());
-        check(gpt_gp_rfft2_log_abs_det_jac_host(ctx(), GPT_COL_MAJOR, cv.data(), H, width, dim1, &value, gc.data()), fn);
-        auto arena_c = stan::math::to_arena(cov);
-        return stan::math::make_callback_var(value,
-                                             [arena_c, gc](auto& vi) mutable { arena_c.adj() += vi.adj() * gc; });
+        stan::math::arena_t<Mat<double, C>> gc(cv.rows(), cv.cols());
+        const double value = b::gp_ladj(cv.data(), s, gc.data());
+        auto ac = stan::math::to_arena(cov);
+        return stan::math::make_callback_var(value, [ac, gc](auto& vi) mutable { ac.adj() += vi.adj() * gc; });
     }
 }
-
-// Spectral kernels: params = (sigma, l1, l2, p1, p2) [2-D] or (sigma, l, p) [1-D]
-template <typename MAT, bool MATERN, typename... Ts>
-inline result_mat_t<MAT, Ts...> spectrum(double nu, int64_t H, int64_t W, int dim1, const double* par, const char* fn,
-                                         const std::function<void(const double*)>& scatter) {
-    using stan::math::var;
-    MAT out;
-    if (dim1) out.resize(W / 2 + 1, 1);
-    else out.resize(H, W / 2 + 1);
-    check(MATERN ? gpt_gp_periodic_matern_cov_rfft2_host(ctx(), GPT_COL_MAJOR, nu, H, W, par, dim1, out.data())
-                 : gpt_gp_periodic_exp_quad_cov_rfft2_host(ctx(), GPT_COL_MAJOR, H, W, par, dim1, out.data()),
-          fn);
-    if constexpr (!any_var<Ts...>::value) {
+// ---- spectral kernels: NP parameters (sigma, length_scale[, ...], period[, ...]) held as vars or doubles -----------
+// `Scatter` is a small functor type (no std::function: the autodiff arena never runs destructors)
+template <int C, bool MATERN, int NP, bool ANYVAR, typename Scatter>
+inline Mat<std::conditional_t<ANYVAR, var, double>, C> spectrum(double nu, b::Shape s, const double (&par)[NP], Scatter scatter) {
+    Mat<double, C> out(s.dim1 ? s.wf() : s.H, s.dim1 ? 1 : s.wf());
+    b::spectrum(MATERN, nu, s, par, out.data());
+    if constexpr (!ANYVAR) {
         return out;
     } else {
-        stan::math::arena_t<Eigen::Matrix<var, MAT::RowsAtCompileTime, MAT::ColsAtCompileTime>> res = out;
-        const int npar = dim1 ? 3 : 5;
-        stan::math::arena_t<Eigen::VectorXd> p(npar);
-        for (int i = 0; i < npar; ++i) p[i] = par[i];
-        stan::math::reverse_pass_callback([res, p, nu, H, W, dim1, fn, scatter]() mutable {
-            const MAT cbar = res.adj();
+        stan::math::arena_t<Mat<var, C>> res = out;
+        stan::math::arena_t<VecD> p(NP);
+        for (int i = 0; i < NP; ++i) p.coeffRef(i) = par[i];
+        stan::math::reverse_pass_callback([res, p, nu, s, scatter]() mutable {
+            const Mat<double, C> cbar = res.adj();
             double pbar[5] = {0, 0, 0, 0, 0};
-            check(MATERN ? gpt_gp_periodic_matern_cov_rfft2_vjp_host(ctx(), GPT_COL_MAJOR, nu, H, W, p.data(),
-                                                                     cbar.data(), dim1, pbar)
-                         : gpt_gp_periodic_exp_quad_cov_rfft2_vjp_host(ctx(), GPT_COL_MAJOR, H, W, p.data(),
-                                                                       cbar.data(), dim1, pbar),
-                  fn);
+            b::spectrum_vjp(MATERN, nu, s, p.data(), cbar.data(), pbar);
             scatter(pbar);
         });
-        return Eigen::Matrix<var, MAT::RowsAtCompileTime, MAT::ColsAtCompileTime>(res);
+        return Mat<var, C>(res);
     }
 }
-
 template <typename T> inline void add_adj(const T& x, double g) {
     if constexpr (stan::is_var<T>::value) x.adj() += g;
 }
+template <typename TS, typename TL, typename TP> struct Scatter1 { // 1-D kernels: three scalars
+    TS sigma;
+    TL ls;
+    TP per;
+    void operator()(const double* g) const {
+        add_adj(sigma, g[0]);
+        add_adj(ls, g[1]);
+        add_adj(per, g[2]);
+    }
+};
+template <typename TS, typename AL, typename AP> struct Scatter2 { // 2-D kernels: a scalar and two arena 2-vectors
+    TS sigma;
+    AL ls;
+    AP per;
+    void operator()(const double* g) {
+        add_adj(sigma, g[0]);
+        if constexpr (is_var_v<AL>) {
+            ls.coeffRef(0).adj() += g[1];
+            ls.coeffRef(1).adj() += g[2];
+        }
+        if constexpr (is_var_v<AP>) {
+            per.coeffRef(0).adj() += g[3];
+            per.coeffRef(1).adj() += g[4];
+        }
+    }
+};
+}  // namespace gptools_hip_stan
 
-}  // namespace gptools_hip_detail
+#define GPT_REQ_VEC(T) stan::is_col_vector<T>, stan::is_vt_not_complex<T>
+#define GPT_REQ_CVEC(T) stan::is_col_vector<T>, stan::is_vt_complex<T>
+#define GPT_REQ_MAT(T) stan::is_eigen_matrix_dynamic<T>, stan::is_vt_not_complex<T>
+#define GPT_REQ_CMAT(T) stan::is_eigen_matrix_dynamic<T>, stan::is_vt_complex<T>
+#define GPT_BASE(T) stan::base_type_t<T>
 
-// ---- fft1.stan ---------------------------------------------------------------------------------------
-template <typename T0__, typename T1__, typename T2__>
-inline auto gp_rfft(const T0__& y, const T1__& loc, const T2__& cov_rfft, std::ostream* pstream__) {
-    return gptools_hip_detail::transform<true, Eigen::VectorXd>(y, loc, cov_rfft, 1, "gp_rfft");
+// ===================================================================================================
+// util.stan:255-330 -- real-FFT layer (differentiable: linear maps)
+template <typename T0__, stan::require_all_t<GPT_REQ_VEC(T0__)>* = nullptr>
+Eigen::Matrix<std::complex<stan::promote_args_t<GPT_BASE(T0__)>>, -1, 1> rfft(const T0__& y, std::ostream* pstream__) {
+    namespace g = gptools_hip_stan;
+    const auto s = g::b::shape1(y.size());
+    return g::real_to_cplx<1>(y, s, s.wf(), 1, g::b::rfft2, g::b::rfft2_vjp);
 }
-template <typename T0__, typename T1__, typename T2__>
-inline auto gp_inv_rfft(const T0__& z, const T1__& loc, const T2__& cov_rfft, std::ostream* pstream__) {
-    return gptools_hip_detail::transform<false, Eigen::VectorXd>(z, loc, cov_rfft, 1, "gp_inv_rfft");
+template <typename T0__, stan::require_all_t<GPT_REQ_CVEC(T0__)>* = nullptr>
+Eigen::Matrix<std::complex<stan::promote_args_t<GPT_BASE(T0__)>>, -1, 1> expand_rfft(const T0__& y, const int& n,
+                                                                                     std::ostream* pstream__) {
+    // util.stan:271-281 on Stan's own containers (a copy and a conjugated, reversed copy: nothing for a GPU to do,
+    // and complex<var> entries keep their varis); the size check is the reference's reject (util.stan:274-276)
+    if (y.size() != n / 2 + 1)
+        throw std::domain_error("expected complex vector with " + std::to_string(n / 2 + 1) + " elements but got " +
+                                std::to_string(y.size()));
+    Eigen::Matrix<std::complex<stan::promote_args_t<GPT_BASE(T0__)>>, -1, 1> out(n);
+    const int nrfft = n / 2 + 1, nc = (n - 1) / 2;
+    for (int k = 0; k < nrfft; ++k) out.coeffRef(k) = y.coeff(k);
+    for (int k = 1; k <= nc; ++k) out.coeffRef(n - k) = stan::math::conj(y.coeff(k));
+    return out;
 }
-template <typename T0__>
-inline auto gp_rfft_log_abs_det_jac(const T0__& cov_rfft, const int& n, std::ostream* pstream__) {
-    return gptools_hip_detail::ladj<Eigen::VectorXd>(cov_rfft, n, 1, "gp_rfft_log_abs_det_jac");
+template <typename T0__, stan::require_all_t<GPT_REQ_CVEC(T0__)>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<GPT_BASE(T0__)>, -1, 1> inv_rfft(const T0__& z, const int& n, std::ostream* pstream__) {
+    namespace g = gptools_hip_stan;
+    const auto s = g::b::shape1(n);
+    g::b::require_sizes(z.size() == s.wf(), "inv_rfft");
+    return g::cplx_to_real<1>(z, s, n, 1, g::b::inv_rfft2, g::b::inv_rfft2_vjp);
 }
-// called as a function in the reference (`y ~ gp_rfft(...)` drops nothing: fft1.stan:100 keeps constants)
-template <bool propto__, typename T0__, typename T1__, typename T2__>
-inline auto gp_rfft_lpdf(const T0__& y, const T1__& loc, const T2__& cov_rfft, std::ostream* pstream__) {
-    return gptools_hip_detail::lpdf<Eigen::VectorXd>(y, loc, cov_rfft, 1, "gp_rfft_lpdf");
+template <typename T0__, stan::require_all_t<GPT_REQ_MAT(T0__)>* = nullptr>
+Eigen::Matrix<std::complex<stan::promote_args_t<GPT_BASE(T0__)>>, -1, -1> rfft2(const T0__& y, std::ostream* pstream__) {
+    namespace g = gptools_hip_stan;
+    const auto s = g::b::shape2(y.rows(), y.cols());
+    return g::real_to_cplx<-1>(y, s, s.H, s.wf(), g::b::rfft2, g::b::rfft2_vjp);
+}
+template <typename T0__, stan::require_all_t<GPT_REQ_CMAT(T0__)>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<GPT_BASE(T0__)>, -1, -1> inv_rfft2(const T0__& z, const int& m, std::ostream* pstream__) {
+    namespace g = gptools_hip_stan;
+    const auto s = g::b::shape2(z.rows(), m);
+    g::b::require_sizes(z.cols() == s.wf(), "inv_rfft2");
+    return g::cplx_to_real<-1>(z, s, s.H, m, g::b::inv_rfft2, g::b::inv_rfft2_vjp);
 }
 
-template <typename T1__, typename T2__, typename T3__>
-inline auto gp_periodic_exp_quad_cov_rfft(const int& n, const T1__& sigma, const T2__& length_scale,
-                                          const T3__& period, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
+// ===================================================================================================
+// fft1.stan
+template <typename T0__, stan::require_all_t<GPT_REQ_VEC(T0__)>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<GPT_BASE(T0__)>, -1, 1> gp_evaluate_rfft_scale(const T0__& cov_rfft, const int& n,
+                                                                                  std::ostream* pstream__) {
+    return gptools_hip_stan::scale<1>(cov_rfft, gptools_hip::shape1(n));
+}
+template <typename T0__, stan::require_all_t<GPT_REQ_CVEC(T0__)>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<GPT_BASE(T0__)>, -1, 1> gp_unpack_rfft(const T0__& x, const int& n, std::ostream* pstream__) {
+    namespace g = gptools_hip_stan;
+    const auto s = g::b::shape1(n);
+    g::b::require_sizes(x.size() == s.wf(), "gp_unpack_rfft");
+    return g::cplx_to_real<1>(x, s, n, 1, g::b::gp_unpack, g::b::gp_unpack_vjp);
+}
+template <typename T0__, stan::require_all_t<GPT_REQ_VEC(T0__)>* = nullptr>
+Eigen::Matrix<std::complex<stan::promote_args_t<GPT_BASE(T0__)>>, -1, 1> gp_pack_rfft(const T0__& z, std::ostream* pstream__) {
+    namespace g = gptools_hip_stan;
+    const auto s = g::b::shape1(z.size());
+    return g::real_to_cplx<1>(z, s, s.wf(), 1, g::b::gp_pack, g::b::gp_pack_vjp);
+}
+template <typename T0__, typename T1__, typename T2__,
+          stan::require_all_t<GPT_REQ_VEC(T0__), GPT_REQ_VEC(T1__), GPT_REQ_VEC(T2__)>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T1__), GPT_BASE(T2__)>, -1, 1> gp_rfft(
+    const T0__& y, const T1__& loc, const T2__& cov_rfft, std::ostream* pstream__) {
+    return gptools_hip_stan::transform<true, 1>(y, loc, cov_rfft, 1, "gp_rfft");
+}
+template <typename T0__, typename T1__, typename T2__,
+          stan::require_all_t<GPT_REQ_VEC(T0__), GPT_REQ_VEC(T1__), GPT_REQ_VEC(T2__)>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T1__), GPT_BASE(T2__)>, -1, 1> gp_inv_rfft(
+    const T0__& z, const T1__& loc, const T2__& cov_rfft, std::ostream* pstream__) {
+    return gptools_hip_stan::transform<false, 1>(z, loc, cov_rfft, 1, "gp_inv_rfft");
+}
+template <typename T0__, stan::require_all_t<GPT_REQ_VEC(T0__)>* = nullptr>
+stan::promote_args_t<GPT_BASE(T0__)> gp_rfft_log_abs_det_jac(const T0__& cov_rfft, const int& n, std::ostream* pstream__) {
+    return gptools_hip_stan::ladj<1>(cov_rfft, gptools_hip::shape1(n));
+}
+// (`y ~ gp_rfft(...)` and the function-call form both keep every constant: fft1.stan:100 calls std_normal_lpdf as a
+// function, so propto__ changes nothing)
+template <bool propto__, typename T0__, typename T1__, typename T2__,
+          stan::require_all_t<GPT_REQ_VEC(T0__), GPT_REQ_VEC(T1__), GPT_REQ_VEC(T2__)>* = nullptr>
+stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T1__), GPT_BASE(T2__)> gp_rfft_lpdf(const T0__& y, const T1__& loc,
+                                                                                    const T2__& cov_rfft,
+                                                                                    std::ostream* pstream__) {
+    return gptools_hip_stan::lpdf<1>(y, loc, cov_rfft, 1, "gp_rfft_lpdf");
+}
+template <typename T1__, typename T2__, typename T3__,
+          stan::require_all_t<stan::is_stan_scalar<T1__>, stan::is_stan_scalar<T2__>, stan::is_stan_scalar<T3__>>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<T1__, T2__, T3__>, -1, 1> gp_periodic_exp_quad_cov_rfft(const int& n, const T1__& sigma,
+                                                                                             const T2__& length_scale,
+                                                                                             const T3__& period,
+                                                                                             std::ostream* pstream__) {
+    namespace g = gptools_hip_stan;
     using stan::math::value_of;
     const double par[3] = {value_of(sigma), value_of(length_scale), value_of(period)};
-    return d::spectrum<Eigen::VectorXd, false, T1__, T2__, T3__>(0.0, 1, n, 1, par, "gp_periodic_exp_quad_cov_rfft",
-                                                                 [sigma, length_scale, period](const double* g) {
-                                                                     d::add_adj(sigma, g[0]);
-                                                                     d::add_adj(length_scale, g[1]);
-                                                                     d::add_adj(period, g[2]);
-                                                                 });
+    return g::spectrum<1, false, 3, g::any_var_v<T1__, T2__, T3__>>(0.0, g::b::shape1(n), par,
+                                                                   g::Scatter1<T1__, T2__, T3__>{sigma, length_scale, period});
 }
-template <typename T0__, typename T2__, typename T3__, typename T4__>
-inline auto gp_periodic_matern_cov_rfft(const T0__& nu, const int& n, const T2__& sigma, const T3__& length_scale,
-                                        const T4__& period, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
+template <typename T0__, typename T2__, typename T3__, typename T4__,
+          stan::require_all_t<stan::is_stan_scalar<T0__>, stan::is_stan_scalar<T2__>, stan::is_stan_scalar<T3__>,
+                              stan::is_stan_scalar<T4__>>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<T0__, T2__, T3__, T4__>, -1, 1> gp_periodic_matern_cov_rfft(
+    const T0__& nu, const int& n, const T2__& sigma, const T3__& length_scale, const T4__& period, std::ostream* pstream__) {
+    namespace g = gptools_hip_stan;
     using stan::math::value_of;
-    d::require_no_var(stan::is_var<T0__>::value, "gp_periodic_matern_cov_rfft (d/dnu)");
+    // nu is a literal in every model of the reference (trees.stan:28, padded.stan:19): data, no d/dnu
+    if (stan::is_var<T0__>::value) throw std::domain_error("gp_periodic_matern_cov_rfft: nu must be data");
     const double par[3] = {value_of(sigma), value_of(length_scale), value_of(period)};
-    return d::spectrum<Eigen::VectorXd, true, T2__, T3__, T4__>(value_of(nu), 1, n, 1, par,
-                                                                "gp_periodic_matern_cov_rfft",
-                                                                [sigma, length_scale, period](const double* g) {
-                                                                    d::add_adj(sigma, g[0]);
-                                                                    d::add_adj(length_scale, g[1]);
-                                                                    d::add_adj(period, g[2]);
-                                                                });
+    return g::spectrum<1, true, 3, g::any_var_v<T0__, T2__, T3__, T4__>>(
+        value_of(nu), g::b::shape1(n), par, g::Scatter1<T2__, T3__, T4__>{sigma, length_scale, period});
 }
 
-// ---- fft2.stan ---------------------------------------------------------------------------------------
-template <typename T0__, typename T1__, typename T2__>
-inline auto gp_rfft2(const T0__& y, const T1__& loc, const T2__& cov_rfft2, std::ostream* pstream__) {
-    return gptools_hip_detail::transform<true, Eigen::MatrixXd>(y, loc, cov_rfft2, 0, "gp_rfft2");
+// ===================================================================================================
+// fft2.stan
+template <typename T0__, stan::require_all_t<GPT_REQ_MAT(T0__)>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<GPT_BASE(T0__)>, -1, -1> gp_evaluate_rfft2_scale(const T0__& cov_rfft2, const int& width,
+                                                                                    std::ostream* pstream__) {
+    return gptools_hip_stan::scale<-1>(cov_rfft2, gptools_hip::shape2(cov_rfft2.rows(), width));
 }
-template <typename T0__, typename T1__, typename T2__>
-inline auto gp_inv_rfft2(const T0__& z, const T1__& loc, const T2__& cov_rfft2, std::ostream* pstream__) {
-    return gptools_hip_detail::transform<false, Eigen::MatrixXd>(z, loc, cov_rfft2, 0, "gp_inv_rfft2");
+template <typename T0__, stan::require_all_t<GPT_REQ_CMAT(T0__)>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<GPT_BASE(T0__)>, -1, -1> gp_unpack_rfft2(const T0__& z, const int& m, std::ostream* pstream__) {
+    namespace g = gptools_hip_stan;
+    const auto s = g::b::shape2(z.rows(), m);
+    g::b::require_sizes(z.cols() == s.wf(), "gp_unpack_rfft2");
+    return g::cplx_to_real<-1>(z, s, s.H, m, g::b::gp_unpack, g::b::gp_unpack_vjp);
 }
-template <typename T0__>
-inline auto gp_rfft2_log_abs_det_jac(const T0__& cov_rfft2, const int& width, std::ostream* pstream__) {
-    return gptools_hip_detail::ladj<Eigen::MatrixXd>(cov_rfft2, width, 0, "gp_rfft2_log_abs_det_jac");
+template <typename T0__, stan::require_all_t<GPT_REQ_MAT(T0__)>* = nullptr>
+Eigen::Matrix<std::complex<stan::promote_args_t<GPT_BASE(T0__)>>, -1, -1> gp_pack_rfft2(const T0__& z, std::ostream* pstream__) {
+    namespace g = gptools_hip_stan;
+    const auto s = g::b::shape2(z.rows(), z.cols());
+    return g::real_to_cplx<-1>(z, s, s.H, s.wf(), g::b::gp_pack, g::b::gp_pack_vjp);
 }
-template <bool propto__, typename T0__, typename T1__, typename T2__>
-inline auto gp_rfft2_lpdf(const T0__& y, const T1__& loc, const T2__& cov_rfft2, std::ostream* pstream__) {
-    return gptools_hip_detail::lpdf<Eigen::MatrixXd>(y, loc, cov_rfft2, 0, "gp_rfft2_lpdf");
+template <typename T0__, typename T1__, typename T2__,
+          stan::require_all_t<GPT_REQ_MAT(T0__), GPT_REQ_MAT(T1__), GPT_REQ_MAT(T2__)>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T1__), GPT_BASE(T2__)>, -1, -1> gp_rfft2(
+    const T0__& y, const T1__& loc, const T2__& cov_rfft2, std::ostream* pstream__) {
+    return gptools_hip_stan::transform<true, -1>(y, loc, cov_rfft2, 0, "gp_rfft2");
 }
-
-template <typename T2__, typename T3__, typename T4__>
-inline auto gp_periodic_exp_quad_cov_rfft2(const int& height, const int& width, const T2__& sigma,
-                                           const T3__& length_scale, const T4__& period, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
+template <typename T0__, typename T1__, typename T2__,
+          stan::require_all_t<GPT_REQ_MAT(T0__), GPT_REQ_MAT(T1__), GPT_REQ_MAT(T2__)>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T1__), GPT_BASE(T2__)>, -1, -1> gp_inv_rfft2(
+    const T0__& z, const T1__& loc, const T2__& cov_rfft2, std::ostream* pstream__) {
+    return gptools_hip_stan::transform<false, -1>(z, loc, cov_rfft2, 0, "gp_inv_rfft2");
+}
+template <typename T0__, stan::require_all_t<GPT_REQ_MAT(T0__)>* = nullptr>
+stan::promote_args_t<GPT_BASE(T0__)> gp_rfft2_log_abs_det_jac(const T0__& cov_rfft2, const int& width, std::ostream* pstream__) {
+    return gptools_hip_stan::ladj<-1>(cov_rfft2, gptools_hip::shape2(cov_rfft2.rows(), width));
+}
+template <bool propto__, typename T0__, typename T1__, typename T2__,
+          stan::require_all_t<GPT_REQ_MAT(T0__), GPT_REQ_MAT(T1__), GPT_REQ_MAT(T2__)>* = nullptr>
+stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T1__), GPT_BASE(T2__)> gp_rfft2_lpdf(const T0__& y, const T1__& loc,
+                                                                                     const T2__& cov_rfft2,
+                                                                                     std::ostream* pstream__) {
+    return gptools_hip_stan::lpdf<-1>(y, loc, cov_rfft2, 0, "gp_rfft2_lpdf");
+}
+template <typename T2__, typename T3__, typename T4__,
+          stan::require_all_t<stan::is_stan_scalar<T2__>, GPT_REQ_VEC(T3__), GPT_REQ_VEC(T4__)>* = nullptr>
+Eigen::Matrix<stan::promote_args_t<T2__, GPT_BASE(T3__), GPT_BASE(T4__)>, -1, -1> gp_periodic_exp_quad_cov_rfft2(
+    const int& height, const int& width, const T2__& sigma, const T3__& length_scale, const T4__& period,
+    std::ostream* pstream__) {
+    namespace g = gptools_hip_stan;
     using stan::math::value_of;
     auto ls = stan::math::to_arena(length_scale);
     auto pd = stan::math::to_arena(period);
-    const double par[5] = {value_of(sigma), value_of(ls[0]), value_of(ls[1]), value_of(pd[0]), value_of(pd[1])};
-    return d::spectrum<Eigen::MatrixXd, false, T2__, T3__, T4__>(0.0, height, width, 0, par,
-                                                                 "gp_periodic_exp_quad_cov_rfft2",
-                                                                 [sigma, ls, pd](const double* g) mutable {
-                                                                     d::add_adj(sigma, g[0]);
-                                                                     d::add_adj(ls.coeffRef(0), g[1]);
-                                                                     d::add_adj(ls.coeffRef(1), g[2]);
-                                                                     d::add_adj(pd.coeffRef(0), g[3]);
-                                                                     d::add_adj(pd.coeffRef(1), g[4]);
-                                                                 });
+    const double par[5] = {value_of(sigma), value_of(ls.coeff(0)), value_of(ls.coeff(1)), value_of(pd.coeff(0)),
+                           value_of(pd.coeff(1))};
+    return g::spectrum<-1, false, 5, g::any_var_v<T2__, T3__, T4__>>(
+        0.0, g::b::shape2(height, width), par, g::Scatter2<T2__, decltype(ls), decltype(pd)>{sigma, ls, pd});
 }
-template <typename T0__, typename T3__, typename T4__, typename T5__>
-inline auto gp_periodic_matern_cov_rfft2(const T0__& nu, const int& height, const int& width, const T3__& sigma,
-                                         const T4__& length_scale, const T5__& period, std::ostream* pstream__) {
-    namespace d = gptools_hip_detail;
+template <typename T0__, typename T3__, typename T4__, typename T5__,
+          stan::require_all_t<stan::is_stan_scalar<T0__>, stan::is_stan_scalar<T3__>, GPT_REQ_VEC(T4__), GPT_REQ_VEC(T5__)>* =
+              nullptr>
+Eigen::Matrix<stan::promote_args_t<T0__, T3__, GPT_BASE(T4__), GPT_BASE(T5__)>, -1, -1> gp_periodic_matern_cov_rfft2(
+    const T0__& nu, const int& height, const int& width, const T3__& sigma, const T4__& length_scale, const T5__& period,
+    std::ostream* pstream__) {
+    namespace g = gptools_hip_stan;
     using stan::math::value_of;
-    d::require_no_var(stan::is_var<T0__>::value, "gp_periodic_matern_cov_rfft2 (d/dnu)");
+    if (stan::is_var<T0__>::value) throw std::domain_error("gp_periodic_matern_cov_rfft2: nu must be data");
     auto ls = stan::math::to_arena(length_scale);
     auto pd = stan::math::to_arena(period);
-    const double par[5] = {value_of(sigma), value_of(ls[0]), value_of(ls[1]), value_of(pd[0]), value_of(pd[1])};
-    return d::spectrum<Eigen::MatrixXd, true, T3__, T4__, T5__>(value_of(nu), height, width, 0, par,
-                                                                "gp_periodic_matern_cov_rfft2",
-                                                                [sigma, ls, pd](const double* g) mutable {
-                                                                    d::add_adj(sigma, g[0]);
-                                                                    d::add_adj(ls.coeffRef(0), g[1]);
-                                                                    d::add_adj(ls.coeffRef(1), g[2]);
-                                                                    d::add_adj(pd.coeffRef(0), g[3]);
-                                                                    d::add_adj(pd.coeffRef(1), g[4]);
-                                                                });
+    const double par[5] = {value_of(sigma), value_of(ls.coeff(0)), value_of(ls.coeff(1)), value_of(pd.coeff(0)),
+                           value_of(pd.coeff(1))};
+    return g::spectrum<-1, true, 5, g::any_var_v<T0__, T3__, T4__, T5__>>(
+        value_of(nu), g::b::shape2(height, width), par, g::Scatter2<T3__, decltype(ls), decltype(pd)>{sigma, ls, pd});
 }
 
-// ---- extension: non-centred model density in one call (gptools/fft_obs.stan; include/gptools_hip.h,
-// gpt_gp_inv_rfft2_obs_lpdf_host). No counterpart in the reference, where docs/trees/trees.stan:31-49 spells the same
-// density as gp_inv_rfft2 + std_normal + a masked neg_binomial_2 loop. Only z, cov and the data travel to the GPU and
-// only the adjoints of z and cov (and four scalars) come back.
-namespace gptools_hip_detail {
-template <typename MAT, typename T0, typename TOBS, typename TLOC, typename TCOV, typename TTH>
+// ===================================================================================================
+// Extension (gptools/fft_obs.stan; no counterpart in the reference, where docs/trees/trees.stan:31-49 spells the same
+// density as gp_inv_rfft2 + std_normal + a masked neg_binomial_2 loop): non-centred model density in one call. Only z,
+// cov and the data travel to the GPU and only the adjoints of z and cov (and four scalars) come back.
+namespace gptools_hip_stan {
+template <int C, typename T0, typename TOBS, typename TLOC, typename TCOV, typename TTH>
 inline stan::return_type_t<T0, TLOC, TCOV, TTH> obs_lpdf(const T0& z, int family, const TOBS& obs, const TLOC& loc,
                                                          const TCOV& cov, const TTH& theta, int prior, int dim1,
                                                          const char* fn) {
-    const MAT zv = val(z), ov = val(obs), cv = val(cov);
-    const int64_t H = height_of(zv, dim1), W = width_of(zv, dim1);
-    const int64_t oh = height_of(ov, dim1), ow = width_of(ov, dim1);
-    if (cv.size() != H * (W / 2 + 1) || oh > H || ow > W || oh < 1 || ow < 1)
-        throw std::invalid_argument(std::string(fn) + ": argument sizes do not match");
-    const double lv = stan::math::value_of(loc), tv = stan::math::value_of(theta);
-    double value = 0.0, gls = 0.0, gth = 0.0;
-    stan::math::arena_t<MAT> gz(zv.rows(), zv.cols()), gc(cv.rows(), cv.cols());
-    check(gpt_gp_inv_rfft2_obs_lpdf_host(ctx(), GPT_COL_MAJOR, family, zv.data(), nullptr, lv, cv.data(), ov.data(), oh, ow,
-                                         tv, prior, H, W, dim1, &value, gz.data(), &gls,
-                                         stan::is_constant<TCOV>::value ? nullptr : gc.data(), &gth),
-          fn);
-    if constexpr (!any_var<T0, TLOC, TCOV, TTH>::value) {
+    const Mat<double, C> zv = real_val<C>(z), ov = real_val<C>(obs), cv = real_val<C>(cov);
+    const b::Shape s{dim1 ? 1 : zv.rows(), dim1 ? zv.size() : zv.cols(), dim1};
+    const int64_t oh = dim1 ? 1 : ov.rows(), ow = dim1 ? ov.size() : ov.cols();
+    b::require_sizes(cv.size() == s.nf() && oh >= 1 && ow >= 1 && oh <= s.H && ow <= s.W, fn);
+    b::ObsGrad og{0.0, 0.0};
+    stan::math::arena_t<Mat<double, C>> gz(zv.rows(), zv.cols()), gc(cv.rows(), cv.cols());
+    const double value = b::obs_lpdf(family, zv.data(), stan::math::value_of(loc), cv.data(), ov.data(), oh, ow,
+                                     stan::math::value_of(theta), prior, s, gz.data(), is_var_v<TCOV> ? gc.data() : nullptr, &og);
+    if constexpr (!any_var_v<T0, TLOC, TCOV, TTH>) {
         return value;
     } else {
-        auto arena_z = stan::math::to_arena(z);
-        auto arena_c = stan::math::to_arena(cov);
-        return stan::math::make_callback_var(value, [arena_z, arena_c, loc, theta, gz, gc, gls, gth](auto& vi) mutable {
-            if constexpr (!stan::is_constant<T0>::value) arena_z.adj() += vi.adj() * gz;
-            if constexpr (!stan::is_constant<TCOV>::value) arena_c.adj() += vi.adj() * gc;
-            add_adj(loc, vi.adj() * gls);
-            add_adj(theta, vi.adj() * gth);
+        auto az = stan::math::to_arena(z);
+        auto ac = stan::math::to_arena(cov);
+        return stan::math::make_callback_var(value, [az, ac, loc, theta, gz, gc, og](auto& vi) mutable {
+            if constexpr (is_var_v<T0>) az.adj() += vi.adj() * gz;
+            if constexpr (is_var_v<TCOV>) ac.adj() += vi.adj() * gc;
+            add_adj(loc, vi.adj() * og.loc_sum);
+            add_adj(theta, vi.adj() * og.theta);
         });
     }
 }
-}  // namespace gptools_hip_detail
-
-template <bool propto__, typename T0__, typename T2__, typename T3__, typename T4__, typename T5__>
-inline auto gp_inv_rfft2_obs_lpdf(const T0__& z, const int& family, const T2__& obs, const T3__& loc,
-                                  const T4__& cov_rfft2, const T5__& theta, const int& prior, std::ostream* pstream__) {
-    return gptools_hip_detail::obs_lpdf<Eigen::MatrixXd>(z, family, obs, loc, cov_rfft2, theta, prior, 0,
-                                                         "gp_inv_rfft2_obs_lpdf");
+}  // namespace gptools_hip_stan
+template <bool propto__, typename T0__, typename T2__, typename T3__, typename T4__, typename T5__,
+          stan::require_all_t<GPT_REQ_MAT(T0__), GPT_REQ_MAT(T2__), stan::is_stan_scalar<T3__>, GPT_REQ_MAT(T4__),
+                              stan::is_stan_scalar<T5__>>* = nullptr>
+stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T2__), T3__, GPT_BASE(T4__), T5__> gp_inv_rfft2_obs_lpdf(
+    const T0__& z, const int& family, const T2__& obs, const T3__& loc, const T4__& cov_rfft2, const T5__& theta,
+    const int& prior, std::ostream* pstream__) {
+    return gptools_hip_stan::obs_lpdf<-1>(z, family, obs, loc, cov_rfft2, theta, prior, 0, "gp_inv_rfft2_obs_lpdf");
 }
-template <bool propto__, typename T0__, typename T2__, typename T3__, typename T4__, typename T5__>
-inline auto gp_inv_rfft_obs_lpdf(const T0__& z, const int& family, const T2__& obs, const T3__& loc,
-                                 const T4__& cov_rfft, const T5__& theta, const int& prior, std::ostream* pstream__) {
-    return gptools_hip_detail::obs_lpdf<Eigen::VectorXd>(z, family, obs, loc, cov_rfft, theta, prior, 1,
-                                                         "gp_inv_rfft_obs_lpdf");
+template <bool propto__, typename T0__, typename T2__, typename T3__, typename T4__, typename T5__,
+          stan::require_all_t<GPT_REQ_VEC(T0__), GPT_REQ_VEC(T2__), stan::is_stan_scalar<T3__>, GPT_REQ_VEC(T4__),
+                              stan::is_stan_scalar<T5__>>* = nullptr>
+stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T2__), T3__, GPT_BASE(T4__), T5__> gp_inv_rfft_obs_lpdf(
+    const T0__& z, const int& family, const T2__& obs, const T3__& loc, const T4__& cov_rfft, const T5__& theta,
+    const int& prior, std::ostream* pstream__) {
+    return gptools_hip_stan::obs_lpdf<1>(z, family, obs, loc, cov_rfft, theta, prior, 1, "gp_inv_rfft_obs_lpdf");
 }
 
+#undef GPT_REQ_VEC
+#undef GPT_REQ_CVEC
+#undef GPT_REQ_MAT
+#undef GPT_REQ_CMAT
+#undef GPT_BASE
 #endif  // GPTOOLS_HIP_HPP

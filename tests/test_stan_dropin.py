@@ -32,14 +32,63 @@ def test_include_dir_resolves_the_reference_include_names():
     assert set(bodies) <= {"gp_rfft_log_abs_det_jacobian", "gp_rfft2_log_abs_det_jacobian"}, bodies
 
 
+def _stan_declarations():
+    """name -> (return type, [(type, name), ...]) of every body-less declaration in the shipped .stan files."""
+    from gptools_amd import stan
+
+    inc = stan.get_include()
+    decls = {}
+    for name in ("fft1.stan", "fft2.stan", "util.stan", "fft_obs.stan"):
+        text = open(os.path.join(inc, "gptools", name)).read()
+        text = re.sub(r"//[^\n]*", "", text)
+        for ret, fn, args in re.findall(r"^\s*(\w+)\s+(\w+)\s*\(([^)]*)\)\s*;", text, re.M):
+            decls[fn] = (ret, [tuple(a.split()) for a in args.split(",")])
+    return decls
+
+
+def _header_definition(hpp, fn):
+    """(template head, return type text, parameter list text) of the definition of `fn` in the user header."""
+    m = re.search(r"template <((?:[^<>]|<(?:[^<>]|<(?:[^<>]|<[^<>]*>)*>)*>)*)>\s*\n?([^;{}]*?)\b" + fn + r"\(([^{]*?)\)\s*\{", hpp)
+    assert m, f"{fn} is not defined in the user header"
+    return m.group(1), m.group(2), m.group(3)
+
+
+# what stanc emits per Stan argument type: constraint macro of the header / how the parameter is spelled
+REQ = {"vector": "GPT_REQ_VEC", "complex_vector": "GPT_REQ_CVEC", "matrix": "GPT_REQ_MAT", "complex_matrix": "GPT_REQ_CMAT",
+       "real": "stan::is_stan_scalar"}
+
+
 def test_user_header_defines_every_declared_function():
+    """Every declaration of the shipped .stan files has a definition in the user header whose template head follows
+    from the declaration the way stanc derives its forward declaration: one type parameter and one constraint per
+    non-int argument, in order; `const int&` for ints; `bool propto__` first on `_lpdf`; trailing pstream__."""
     from gptools_amd import stan
 
     hpp = open(stan.get_user_header()).read()
-    for fn in HOT_PATH_FUNCTIONS:
-        assert re.search(rf"\b{fn}\s*\(", hpp) or re.search(rf"GPTOOLS_HIP_SCALE\({fn}\b", hpp), fn
-    # it binds the C ABI, not anything CPU-side
-    assert "gpt_gp_rfft2_lpdf_host" in hpp and "gp_oracle" not in hpp
+    decls = _stan_declarations()
+    for fn in HOT_PATH_FUNCTIONS + ["gp_inv_rfft2_obs_lpdf", "gp_inv_rfft_obs_lpdf"]:
+        assert fn in decls, f"{fn} is not declared in the .stan files"
+        ret, args = decls[fn]
+        head, rtype, params = _header_definition(hpp, fn)
+        tparams = re.findall(r"typename (T\d+__)", head)
+        want_t = [f"T{i}__" for i, (t, _) in enumerate(args) if t != "int"]
+        assert tparams == want_t, (fn, tparams, want_t)
+        assert head.lstrip().startswith("bool propto__") == fn.endswith("_lpdf"), fn
+        constraints = re.findall(r"(GPT_REQ_\w+|stan::is_stan_scalar)[(<](T\d+__)", head)
+        assert constraints == [(REQ[t], f"T{i}__") for i, (t, _) in enumerate(args) if t != "int"], (fn, constraints)
+        plist = [p.strip() for p in params.split(",")]
+        assert plist[-1] == "std::ostream* pstream__", fn
+        for i, ((t, name), p) in enumerate(zip(args, plist)):
+            assert p == (f"const int& {name}" if t == "int" else f"const T{i}__& {name}"), (fn, p)
+        # return type: complex containers spell std::complex<promote_args_t<...>>, reals a bare promote_args_t
+        assert ("std::complex" in rtype) == ret.startswith("complex"), (fn, rtype)
+        assert ("Eigen::Matrix" in rtype) == (ret != "real"), (fn, rtype)
+        assert "stan::promote_args_t" in rtype and "auto" not in rtype.split(), (fn, rtype)
+    # the Stan-typed veneer holds no C-ABI call of its own: everything goes through the compiled, tested bind header
+    bind = open(os.path.join(os.path.dirname(stan.get_user_header()), "gptools_hip_bind.hpp")).read()
+    assert "#include <gptools_hip_bind.hpp>" in hpp and not re.search(r"\bgpt_\w+_host\(", hpp)
+    assert "gpt_gp_rfft2_lpdf_host" in bind and "#include <stan" not in bind and "Eigen::" not in bind
+    assert "gp_oracle" not in hpp + bind and "std::function" not in hpp.replace("no std::function", "")
 
 
 def test_compile_model_needs_cmdstanpy_but_import_does_not():
@@ -63,7 +112,8 @@ def test_observation_model_extension_is_declared_and_bound():
     hpp = open(stan.get_user_header()).read()
     for fn in ("gp_inv_rfft2_obs_lpdf", "gp_inv_rfft_obs_lpdf"):
         assert re.search(rf"^real {fn}\(", text, re.M), fn
-        assert re.search(rf"inline auto {fn}\(", hpp), fn
-    assert "gpt_gp_inv_rfft2_obs_lpdf_host" in hpp
+        assert re.search(rf"\b{fn}\(", hpp), fn
+    bind = open(os.path.join(os.path.dirname(stan.get_user_header()), "gptools_hip_bind.hpp")).read()
+    assert "gpt_gp_inv_rfft2_obs_lpdf_host" in bind
     # the reference's own include names stay free of the extension: existing models compile unchanged
     assert "fft_obs" not in open(os.path.join(inc, "gptools", "fft.stan")).read()
