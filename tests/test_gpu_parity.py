@@ -212,7 +212,8 @@ def test_host_entry_points_col_major(fft):
     lib = _lib.load()
     ctx = fft.get_context()
     rng = np.random.default_rng(11)
-    for (h, w, dim1) in [(5, 8, 0), (6, 7, 0), (35, 60, 0), (1, 9, 1), (1, 128, 1)]:
+    # (the last two are large enough for the pinned, chunked staging ring: one exact chunk, and chunks with a remainder)
+    for (h, w, dim1) in [(5, 8, 0), (6, 7, 0), (35, 60, 0), (1, 9, 1), (1, 128, 1), (1024, 1024, 0), (1100, 1000, 0)]:
         wf = w // 2 + 1
         y = rng.normal(size=(h, w))
         loc = rng.normal(size=(h, w))
