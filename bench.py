@@ -117,10 +117,19 @@ def slab_bench(args, fft, device, world, rank, distributed):
     g.manual_seed(11 + rank)
     loc = torch.randn(rows, w, dtype=torch.float64, device=device, generator=g)
     y = loc + torch.randn(rows, w, dtype=torch.float64, device=device, generator=g)
-    out_cov = torch.empty(h, w // 2 + 1, dtype=torch.float64, device=device)
+    if world > 1:  # a rank keeps only its own columns of the spectrum (and of d/dcov)
+        cov_cols, cov_nyq = slab.own_columns(cov, rank, world)
+        del cov
+        torch.cuda.empty_cache()
 
-    def step():
-        return slab.gp_rfft2_lpdf_vjp_slab(y, loc, cov, h, w, comm=comm, out_cov=out_cov)
+        def step():
+            lp_, gy_, mn_, _, _ = slab.gp_rfft2_lpdf_vjp_slab_owned(y, loc, cov_cols, cov_nyq, h, w, comm=comm)
+            return lp_, gy_, mn_
+    else:
+        out_cov = torch.empty(h, w // 2 + 1, dtype=torch.float64, device=device)
+
+        def step():
+            return slab.gp_rfft2_lpdf_vjp_slab(y, loc, cov, h, w, comm=comm, out_cov=out_cov)
 
     def barrier():
         if distributed:

@@ -69,6 +69,9 @@ _SIGNATURES = {
     "gpt_slab_rows_fwd": [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64],
     "gpt_slab_cols_lpdf_vjp": [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr],
     "gpt_slab_rows_inv": [c_ptr, c_i64, c_i64, c_i64, c_i64, c_dbl, c_ptr],
+    "gpt_slab_rows_fwd_blocked": [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64],
+    "gpt_slab_cols_lpdf_vjp_owned": [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr],
+    "gpt_slab_rows_inv_blocked": [c_ptr, c_i64, c_i64, c_i64, c_i64, c_dbl, c_ptr],
 }
 # entry points without the leading context argument / with other return types
 _PLAIN = {

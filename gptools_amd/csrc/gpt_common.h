@@ -90,7 +90,20 @@ struct LatArgs {
                    // into d/d(sigma, length_scale, period))
     // Twiddle table w_{H/4}^m of the sub-line column kernels (gpt_pow2_sub.h); null: whole-column kernels only.
     const cplx* tw_sub;
+    // Slab decomposition, layouts that need no copy on either side of the exchange (0 = not used):
+    //  * spec_cshift, spec_blk: the row kernels address packed column j of a spectrum row at
+    //    (j >> spec_cshift) * spec_blk + (j & mask) instead of j -- the [rank][rows][columns per rank] layout an
+    //    all-to-all sends and receives;
+    //  * cov_ld: row stride of cov / d/dcov when a rank holds only its own columns ([H][cov_ld], the pointers shifted so
+    //    that lattice column numbers still index them) instead of the lattice's H x (W/2+1) arrays.
+    int spec_cshift, spec_blk;
+    int cov_ld;
 };
+// offset of packed column j inside a spectrum row (see LatArgs::spec_cshift)
+__device__ __forceinline__ unsigned spec_col(const LatArgs& a, int j) {
+    return a.spec_cshift ? ((unsigned)j >> a.spec_cshift) * (unsigned)a.spec_blk + ((unsigned)j & ((1u << a.spec_cshift) - 1u))
+                         : (unsigned)j;
+}
 
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
@@ -225,7 +238,7 @@ __device__ __forceinline__ ZLayout make_layout(const LatArgs& a) {
     ZLayout L;
     L.H = a.H;
     L.W = a.W;
-    L.Wf = a.W / 2 + 1;
+    L.Wf = a.cov_ld ? a.cov_ld : a.W / 2 + 1; // (row stride of the H x Wf arrays: cov, d/dcov, complex in / out)
     L.Hf = a.H / 2 + 1;
     L.wc = (a.W - 1) / 2;
     L.hc = (a.H - 1) / 2;

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) longrow_fwd1(const double* __restrict__ y
 
 // tmp[pair][j % 8][j / 8] = Z[j] -> packed half spectrum rows 2 pair, 2 pair + 1 (column 0 = DC + i Nyquist)
 __global__ void __launch_bounds__(256) longrow_split(const cplx* __restrict__ tmp, int W, cplx* __restrict__ spec,
-                                                     int64_t ld) {
+                                                     int64_t ld, int cshift, int blk) {
     const int WS = W / RW;
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int64_t pair = blockIdx.y;
@@ -89,14 +89,16 @@ __global__ void __launch_bounds__(256) longrow_split(const cplx* __restrict__ tm
     cplx* s0 = spec + 2 * pair * ld;
     cplx* s1 = s0 + ld;
     const cplx a = at(j);
+    // (blocked layout of the exchange: column j lives at (j >> cshift) * blk + (j & mask), LatArgs::spec_cshift)
+    const unsigned jo = cshift ? ((unsigned)j >> cshift) * (unsigned)blk + ((unsigned)j & ((1u << cshift) - 1u)) : (unsigned)j;
     if (j == 0) {
         const cplx zn = at(W / 2);
         s0[0] = make_double2(a.x, zn.x);
         s1[0] = make_double2(a.y, zn.y);
     } else {
         const cplx c = at(W - j);
-        s0[j] = make_double2(0.5 * (a.x + c.x), 0.5 * (a.y - c.y));
-        s1[j] = make_double2(0.5 * (a.y + c.y), -0.5 * (a.x - c.x));
+        s0[jo] = make_double2(0.5 * (a.x + c.x), 0.5 * (a.y - c.y));
+        s1[jo] = make_double2(0.5 * (a.y + c.y), -0.5 * (a.x - c.x));
     }
 }
 
@@ -104,7 +106,7 @@ __global__ void __launch_bounds__(256) longrow_split(const cplx* __restrict__ tm
 // One thread = one frequency j: a wave reads 64 consecutive frequencies (the mirrored half descending) and writes eight
 // 128-byte pieces, one per sub-line -- the access pattern of longrow_split, mirrored.
 __global__ void __launch_bounds__(256) longrow_merge(const cplx* __restrict__ spec, int64_t ld, int W,
-                                                     cplx* __restrict__ tmp) {
+                                                     cplx* __restrict__ tmp, int cshift, int blk) {
     const int WS = W / RW;
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int64_t pair = blockIdx.y;
@@ -112,12 +114,16 @@ __global__ void __launch_bounds__(256) longrow_merge(const cplx* __restrict__ sp
     const cplx* s0 = spec + 2 * pair * ld;
     const cplx* s1 = s0 + ld;
     cplx v;
+    auto so = [&](int c) -> unsigned {
+        return cshift ? ((unsigned)c >> cshift) * (unsigned)blk + ((unsigned)c & ((1u << cshift) - 1u)) : (unsigned)c;
+    };
     if (j < W / 2) {
-        const cplx A = s0[j], B = s1[j];
+        const cplx A = s0[so(j)], B = s1[so(j)];
         v = j == 0 ? make_double2(A.x, B.x) : make_double2(A.x - B.y, A.y + B.x);
     } else {
         const int m = W - j; // 1 .. W/2
-        const cplx A = s0[m == W / 2 ? 0 : m], B = s1[m == W / 2 ? 0 : m];
+        const unsigned mo = so(m == W / 2 ? 0 : m);
+        const cplx A = s0[mo], B = s1[mo];
         v = m == W / 2 ? make_double2(A.y, B.y) : make_double2(A.x + B.y, -A.y + B.x);
     }
     tmp[pair * W + (int64_t)(j % RW) * WS + j / RW] = v;
@@ -176,14 +182,16 @@ hipError_t gpt_long_row_fwd1(const double* y, const double* loc, int64_t rows, i
     hipLaunchKernelGGL(longrow_fwd1, grid, dim3(256), 0, st, y, loc, W, tmp, twW);
     return hipGetLastError();
 }
-hipError_t gpt_long_row_split(const cplx* tmp, int64_t rows, int W, cplx* spec, int64_t ld, hipStream_t st) {
+hipError_t gpt_long_row_split(const cplx* tmp, int64_t rows, int W, cplx* spec, int64_t ld, int cshift, int blk,
+                              hipStream_t st) {
     dim3 grid((unsigned)((W / 2 + 255) / 256), (unsigned)(rows / 2));
-    hipLaunchKernelGGL(longrow_split, grid, dim3(256), 0, st, tmp, W, spec, ld);
+    hipLaunchKernelGGL(longrow_split, grid, dim3(256), 0, st, tmp, W, spec, ld, cshift, blk);
     return hipGetLastError();
 }
-hipError_t gpt_long_row_merge(const cplx* spec, int64_t ld, int64_t rows, int W, cplx* tmp, hipStream_t st) {
+hipError_t gpt_long_row_merge(const cplx* spec, int64_t ld, int64_t rows, int W, cplx* tmp, int cshift, int blk,
+                              hipStream_t st) {
     dim3 grid((unsigned)((W + 255) / 256), (unsigned)(rows / 2));
-    hipLaunchKernelGGL(longrow_merge, grid, dim3(256), 0, st, spec, ld, W, tmp);
+    hipLaunchKernelGGL(longrow_merge, grid, dim3(256), 0, st, spec, ld, W, tmp, cshift, blk);
     return hipGetLastError();
 }
 hipError_t gpt_long_row_inv3(const cplx* tmp, int64_t rows, int W, double alpha, double* out, const cplx* twW,

@@ -186,8 +186,10 @@ hipError_t gpt_long_rowstep(bool inverse, int R, cplx* spec, int64_t ld, int HS,
 int gpt_long_row_radix();
 hipError_t gpt_long_row_fwd1(const double* y, const double* loc, int64_t rows, int W, cplx* tmp, const cplx* twW,
                              hipStream_t st);
-hipError_t gpt_long_row_split(const cplx* tmp, int64_t rows, int W, cplx* spec, int64_t ld, hipStream_t st);
-hipError_t gpt_long_row_merge(const cplx* spec, int64_t ld, int64_t rows, int W, cplx* tmp, hipStream_t st);
+hipError_t gpt_long_row_split(const cplx* tmp, int64_t rows, int W, cplx* spec, int64_t ld, int cshift, int blk,
+                              hipStream_t st);
+hipError_t gpt_long_row_merge(const cplx* spec, int64_t ld, int64_t rows, int W, cplx* tmp, int cshift, int blk,
+                              hipStream_t st);
 hipError_t gpt_long_row_inv3(const cplx* tmp, int64_t rows, int W, double alpha, double* out, const cplx* twW,
                              hipStream_t st);
 static int long_min() {
@@ -251,7 +253,8 @@ int gpt_slab_col_blocks(int H, int ncols, int cus) {
 // Long lines: `tmp` = scratch of gpt_long_row_tmp_elems complex (passes 0, 2), a.tw_sub = twiddles of the
 // sub-line length (W / 8 for the row passes, H / R for the column pass).
 hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, int ld, double alpha, double* partials,
-                              int cus, cplx* tmp, hipStream_t st) {
+                              int cus, cplx* tmp, double* edge, hipStream_t st) {
+    const int edge_flags = edge ? 3 : 0; // pass 1: cov of the two self-mirrored columns staged by the caller, their d/dcov returned
     if (pass == 0 || pass == 2) {
         const int RWd = gpt_long_row_split_radix(a.W);
         if (RWd < 0) return hipErrorInvalidValue;
@@ -264,9 +267,9 @@ hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, in
                 if (e != hipSuccess) return e;
                 e = sub_by_size(a.W / RWd, [&](auto l) { return decltype(l)::line_fft(false, tmp, nlines, a.tw_sub, st); });
                 if (e != hipSuccess) return e;
-                return gpt_long_row_split(tmp, rows, a.W, spec, ld, st);
+                return gpt_long_row_split(tmp, rows, a.W, spec, ld, a.spec_cshift, a.spec_blk, st);
             }
-            e = gpt_long_row_merge(spec, ld, rows, a.W, tmp, st);
+            e = gpt_long_row_merge(spec, ld, rows, a.W, tmp, a.spec_cshift, a.spec_blk, st);
             if (e != hipSuccess) return e;
             e = sub_by_size(a.W / RWd, [&](auto l) { return decltype(l)::line_fft(true, tmp, nlines, a.tw_sub, st); });
             if (e != hipSuccess) return e;
@@ -285,11 +288,11 @@ hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, in
             const int HS = a.H / R;
             e = gpt_long_rowstep(false, R, spec, ld, HS, a.ncols, a.ph.tw, st);
             if (e != hipSuccess) return e;
-            e = sub_by_size(HS, [&](auto l) { return decltype(l)::colsub(op, a, R, spec, ld, a.tw_sub, partials, nblk, nullptr, 0, st); });
+            e = sub_by_size(HS, [&](auto l) { return decltype(l)::colsub(op, a, R, spec, ld, a.tw_sub, partials, nblk, edge, edge_flags, st); });
             if (e != hipSuccess) return e;
             e = gpt_long_rowstep(true, R, spec, ld, HS, a.ncols, a.ph.tw, st);
         } else {
-            e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, spec, ld, partials, nblk, nullptr, 0, st); });
+            e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, spec, ld, partials, nblk, edge, edge_flags, st); });
         }
         if (e != hipSuccess) return e;
         return gpt_launch_finalize(partials, nblk, 1, 1, 0.0, a.out_lpdf, a.min_eig, st);

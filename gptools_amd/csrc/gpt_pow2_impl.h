@@ -476,12 +476,13 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
             za = make_double2(0.5 * (z.x + zc[m].x), 0.5 * (z.y - zc[m].y));
             zb = make_double2(0.5 * (z.y + zc[m].y), -0.5 * (z.x - zc[m].x));
         }
+        const unsigned jo = spec_col(a, j);
         if (SUB2) {
-            rows_st<NTS>(&s0[j], cadd(za, zb));
-            rows_st<NTS>(&s1[j], cmul(csub(za, zb), wr));
+            rows_st<NTS>(&s0[jo], cadd(za, zb));
+            rows_st<NTS>(&s1[jo], cmul(csub(za, zb), wr));
         } else {
-            rows_st<NTS>(&s0[j], za);
-            rows_st<NTS>(&s1[j], zb);
+            rows_st<NTS>(&s0[jo], za);
+            rows_st<NTS>(&s1[jo], zb);
         }
     }
 }
@@ -516,7 +517,8 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
         const int j = t + T * m;
         const int q = W - j; // 1 .. W/2 when m >= E/2
         const int col = m < E / 2 ? j : (q == W / 2 ? 0 : q);
-        cplx A = s0[col], B = s1[col];
+        const unsigned co = spec_col(a, col);
+        cplx A = s0[co], B = s1[co];
         if (SUB2) {
             const cplx u = cmul(B, wr);
             B = csub(A, u);

@@ -11,8 +11,9 @@ the W/2 + 1 frequencies split evenly). One evaluation:
 
 The local passes are the HIP kernels of the single-GPU path (C ABI `gpt_slab_*`); the exchanges are
 `torch.distributed.all_to_all_single` (RCCL over xGMI with the nccl backend; gloo in the CPU tests, where the
-tests plug in their own local passes). `cov` / `d/dcov` keep the lattice's own H x (W/2+1) layout on every
-rank; a rank touches only its columns (and column W/2 on rank 0).
+tests plug in their own local passes). Nothing is replicated and nothing is copied between layouts: the row kernels
+write / read the all-to-all's own (rank, rows, columns) buffers, and a rank holds only its W/(2G) columns of `cov` /
+`d/dcov` (`gp_rfft2_lpdf_vjp_slab_owned`; rank 0 also holds column W/2, which travels with packed column 0).
 
 Supported sizes: power-of-two heights and widths in 256..32768. Lines of more than 8192 (columns) / 16384 (rows)
 points, i.e. config 5's 32768 x 32768, take the four-step route of csrc/gpt_long.hip.
@@ -28,8 +29,48 @@ from . import fft as _fft
 
 
 class HipStages:
-    """The three local passes on the GPU (device tensors, the context's stream)."""
+    """The three local passes on the GPU (device tensors, the context's stream), on the layouts of the exchange: the row
+    passes write / read the (ranks, rows, columns per rank) buffers the all-to-all sends and receives, the column pass
+    works on the rank's own columns of cov and d/dcov."""
 
+    def rows_fwd_blocked(self, y_rows, loc_rows, height, width, world):
+        rows, nc = y_rows.shape[0], width // 2 // world
+        send = torch.empty(world, rows, nc, dtype=torch.complex128, device=y_rows.device)
+        ctx = _fft.get_context(y_rows.device)
+        ctx.call("gpt_slab_rows_fwd_blocked", _fft._p(y_rows), _fft._p(loc_rows), rows, height, width, _fft._p(send), nc)
+        return send
+
+    def cols_lpdf_vjp_owned(self, spec_cols, cov_cols, cov_nyquist, height, width, col0, need_cov_grad=True):
+        """spec_cols (H, nc) in place; cov_cols (H, nc) = this rank's columns of cov; cov_nyquist (H,) = column W/2, on
+        the rank with col0 == 0 only. Returns (lpdf partial, min partial, d/dcov of the columns or None, d/dcov of
+        column W/2 or None)."""
+        ncols = spec_cols.shape[1]
+        dev = spec_cols.device
+        lp = torch.empty(1, dtype=torch.float64, device=dev)
+        mn = torch.empty(1, dtype=torch.float64, device=dev)
+        out_cols = torch.empty_like(cov_cols) if need_cov_grad else None
+        edge = None
+        if col0 == 0:
+            edge = torch.empty(4, height, dtype=torch.float64, device=dev)
+            edge[0].copy_(cov_cols[:, 0])
+            edge[1].copy_(cov_nyquist)
+        ctx = _fft.get_context(dev)
+        ctx.call("gpt_slab_cols_lpdf_vjp_owned", _fft._p(spec_cols), ncols, _fft._p(cov_cols), _fft._p(out_cols),
+                 cov_cols.shape[1], _fft._p(edge), height, width, col0, ncols, _fft._p(lp), _fft._p(mn))
+        out_nyq = None
+        if col0 == 0 and need_cov_grad:
+            out_cols[:, 0].copy_(edge[2])
+            out_nyq = edge[3].clone()
+        return lp, mn, out_cols, out_nyq
+
+    def rows_inv_blocked(self, recv, height, width, alpha):
+        world, rows, nc = recv.shape
+        out = torch.empty(rows, width, dtype=torch.float64, device=recv.device)
+        ctx = _fft.get_context(recv.device)
+        ctx.call("gpt_slab_rows_inv_blocked", _fft._p(recv), nc, rows, height, width, float(alpha), _fft._p(out))
+        return out
+
+    # --- the plain-layout calls (spec[rows][ld], whole-lattice cov): kept for callers with their own exchange
     def rows_fwd(self, y_rows, loc_rows, height, width):
         rows = y_rows.shape[0]
         spec = torch.empty(rows, width // 2, dtype=torch.complex128, device=y_rows.device)
@@ -53,7 +94,6 @@ class HipStages:
         ctx = _fft.get_context(spec_rows.device)
         ctx.call("gpt_slab_rows_inv", _fft._p(spec_rows), width // 2, rows, height, width, float(alpha), _fft._p(out))
         return out
-
 
     def whole_lattice(self, y, loc, cov, out_cov, height, width, alpha):
         """All three passes on one device (world size 1): no exchange, and the spectrum rows are padded by 8 columns
@@ -157,19 +197,53 @@ def slab_shapes(height, width, world):
     return height // world, wc // world
 
 
-def gp_rfft2_lpdf_vjp_slab(y_rows, loc_rows, cov_rfft2, height, width, comm=None, stages=None, out_cov=None):
-    """Value and gradients of `gp_rfft2_lpdf` (fft2.stan:189-192) for one lattice split over `comm.world` ranks.
+def own_columns(cov_rfft2, rank, world):
+    """A rank's share of a whole-lattice (H, W/2 + 1) spectrum: (its packed columns as a contiguous (H, W/(2 G)) array,
+    column W/2 on rank 0 or None). Column W/2 (Nyquist) rides with packed column 0 (DC + i Nyquist), so rank 0 owns both."""
+    wf = cov_rfft2.shape[-1]
+    nc = (wf - 1) // world
+    cols = cov_rfft2[:, rank * nc:(rank + 1) * nc].contiguous()
+    return cols, (cov_rfft2[:, wf - 1].contiguous() if rank == 0 else None)
 
-    y_rows, loc_rows: this rank's rows, shape (H / G, W). cov_rfft2: (H, W/2 + 1), valid at least in this rank's
-    packed columns [g W'/G, (g+1) W'/G) (and in column W/2 on rank 0). Returns (lpdf, d/dy of this rank's rows,
-    min over the lattice of n c / 2); `out_cov` (H, W/2+1), if given, receives d/dcov in this rank's columns.
-    d/dloc = -d/dy. lpdf and the minimum are identical on all ranks."""
+
+def gp_rfft2_lpdf_vjp_slab_owned(y_rows, loc_rows, cov_cols, cov_nyquist, height, width, comm=None, stages=None,
+                                 need_cov_grad=True):
+    """Value and gradients of `gp_rfft2_lpdf` (fft2.stan:189-192) for one lattice split over `comm.world` ranks, every
+    array in the layout its owner needs and nothing replicated.
+
+    y_rows, loc_rows: this rank's rows, (H / G, W). cov_cols: this rank's packed columns of the spectrum,
+    (H, W / (2 G)) (`own_columns`); cov_nyquist: column W/2, (H,), on rank 0, None elsewhere. Returns (lpdf, d/dy of this
+    rank's rows, min over the lattice of n c / 2, d/dcov of this rank's columns, d/dcov of column W/2 on rank 0);
+    d/dloc = -d/dy; lpdf and the minimum are identical on all ranks. The row passes write and read the all-to-all's own
+    (G, rows, columns) buffers: no layout copies on either side of the two exchanges."""
     comm = comm or SingleComm()
     stages = stages or HipStages()
     world, rank = comm.world, comm.rank
     rows, nc = slab_shapes(height, width, world)
     if tuple(y_rows.shape) != (rows, width) or tuple(loc_rows.shape) != (rows, width):
         raise ValueError(f"rank {rank} must pass its {rows} x {width} rows of y and loc")
+    if tuple(cov_cols.shape) != (height, nc) or (rank == 0) != (cov_nyquist is not None):
+        raise ValueError(f"rank {rank} must pass its {height} x {nc} columns of cov (rank 0: and column W/2)")
+    n = height * width
+    send = stages.rows_fwd_blocked(y_rows.contiguous(), loc_rows.contiguous(), height, width, world)  # (G, rows, nc)
+    cols = comm.all_to_all(send).reshape(height, nc)                                      # all rows, my columns
+    lp, mn, dcov_cols, dcov_nyq = stages.cols_lpdf_vjp_owned(cols, cov_cols.contiguous(), cov_nyquist, height, width,
+                                                             rank * nc, need_cov_grad)
+    back = comm.all_to_all(cols.view(world, rows, nc))                                    # (G, rows, nc): my rows
+    grad_rows = stages.rows_inv_blocked(back, height, width, -1.0 / n)
+    lp = comm.all_reduce_sum(lp.clone()) - 0.5 * n * math.log(2.0 * math.pi)
+    mn = comm.all_reduce_min(mn.clone())
+    return lp.reshape(()), grad_rows, mn.reshape(()), dcov_cols, dcov_nyq
+
+
+def gp_rfft2_lpdf_vjp_slab(y_rows, loc_rows, cov_rfft2, height, width, comm=None, stages=None, out_cov=None):
+    """`gp_rfft2_lpdf_vjp_slab_owned` for callers that hold the whole (H, W/2 + 1) spectrum on every rank: the rank's
+    columns are cut out of `cov_rfft2` and, if `out_cov` (H, W/2+1) is given, d/dcov is written back into this rank's
+    columns of it. Returns (lpdf, d/dy of this rank's rows, min over the lattice of n c / 2)."""
+    comm = comm or SingleComm()
+    stages = stages or HipStages()
+    world, rank = comm.world, comm.rank
+    rows, nc = slab_shapes(height, width, world)
     if tuple(cov_rfft2.shape) != (height, width // 2 + 1):
         raise ValueError("cov_rfft2 keeps the lattice's own (height, width / 2 + 1) layout on every rank")
     n = height * width
@@ -177,14 +251,12 @@ def gp_rfft2_lpdf_vjp_slab(y_rows, loc_rows, cov_rfft2, height, width, comm=None
         lp, grad_rows, mn = stages.whole_lattice(y_rows.contiguous(), loc_rows.contiguous(), cov_rfft2.contiguous(),
                                                  out_cov, height, width, -1.0 / n)
         return (lp - 0.5 * n * math.log(2.0 * math.pi)).reshape(()), grad_rows, mn.reshape(())
-    # rows -> packed half spectrum of my rows, cut into the column blocks of the ranks
-    spec = stages.rows_fwd(y_rows.contiguous(), loc_rows.contiguous(), height, width)      # (rows, W')
-    send = spec.view(rows, world, nc).permute(1, 0, 2).contiguous()                       # (G, rows, nc)
-    cols = comm.all_to_all(send).reshape(height, nc)                                      # all rows, my columns
-    lp, mn = stages.cols_lpdf_vjp(cols, cov_rfft2.contiguous(), out_cov, height, width, rank * nc)
-    back = comm.all_to_all(cols.view(world, rows, nc))                                    # (G, rows, nc): my rows
-    spec = back.permute(1, 0, 2).contiguous().view(rows, world * nc)
-    grad_rows = stages.rows_inv(spec, height, width, -1.0 / n)
-    lp = comm.all_reduce_sum(lp.clone()) - 0.5 * n * math.log(2.0 * math.pi)
-    mn = comm.all_reduce_min(mn.clone())
-    return lp.reshape(()), grad_rows, mn.reshape(())
+    cov_cols, cov_nyq = own_columns(cov_rfft2, rank, world)
+    lp, grad_rows, mn, dcols, dnyq = gp_rfft2_lpdf_vjp_slab_owned(y_rows, loc_rows, cov_cols, cov_nyq, height, width,
+                                                                  comm=comm, stages=stages,
+                                                                  need_cov_grad=out_cov is not None)
+    if out_cov is not None:
+        out_cov[:, rank * nc:(rank + 1) * nc] = dcols
+        if rank == 0:
+            out_cov[:, width // 2] = dnyq
+    return lp, grad_rows, mn

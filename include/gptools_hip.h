@@ -95,6 +95,22 @@ int gpt_slab_cols_lpdf_vjp(gpt_ctx*, double* spec, int64_t ld, const double* cov
                            int64_t width, int64_t col0, int64_t ncols, double* lpdf_partial, double* min_partial);
 int gpt_slab_rows_inv(gpt_ctx*, const double* spec, int64_t ld, int64_t rows, int64_t height, int64_t width,
                       double alpha, double* out);
+/* The same three passes on layouts that need no copy on either side of the all-to-all and no replicated cov:
+ *   gpt_slab_rows_fwd_blocked / gpt_slab_rows_inv_blocked: spec is [width / 2 / block_cols][rows][block_cols] -- block p
+ *       holds this rank's rows of the packed columns rank p owns (block_cols = width / 2 / ranks, a power of two): the
+ *       send buffer of the first exchange, the receive buffer of the second;
+ *   gpt_slab_cols_lpdf_vjp_owned: cov_cols / out_cov_cols (may be NULL) are [height][cov_ld] arrays holding ONLY this
+ *       rank's lattice columns col0 .. col0 + ncols - 1. The two self-mirrored columns 0 and width / 2 belong to the rank
+ *       with col0 == 0, which passes `edge` = 4 * height doubles: cov[:, 0], cov[:, width / 2] on entry (first 2 * height),
+ *       d/dcov of the same two columns on return (last 2 * height); column 0 of its cov_cols / out_cov_cols is then
+ *       neither read nor written. Other ranks pass NULL. */
+int gpt_slab_rows_fwd_blocked(gpt_ctx*, const double* y, const double* loc, int64_t rows, int64_t height, int64_t width,
+                              double* spec, int64_t block_cols);
+int gpt_slab_cols_lpdf_vjp_owned(gpt_ctx*, double* spec, int64_t ld, const double* cov_cols, double* out_cov_cols,
+                                 int64_t cov_ld, double* edge, int64_t height, int64_t width, int64_t col0,
+                                 int64_t ncols, double* lpdf_partial, double* min_partial);
+int gpt_slab_rows_inv_blocked(gpt_ctx*, const double* spec, int64_t block_cols, int64_t rows, int64_t height,
+                              int64_t width, double alpha, double* out);
 
 /* ---- cross-chain batching (no counterpart in the reference, where every chain evaluates
  * gp_rfft(2)_lpdf on its own CPU core) ---------------------------------------------------------------------

@@ -11,6 +11,28 @@ import gp_oracle as oracle  # noqa: E402
 
 
 class NumpyStages:
+    # the layouts of the exchange, built on the plain stand-ins below (copies are fine in a test stand-in)
+    def rows_fwd_blocked(self, y_rows, loc_rows, height, width, world):
+        spec = self.rows_fwd(y_rows, loc_rows, height, width)
+        rows, nc = spec.shape[0], width // 2 // world
+        return spec.view(rows, world, nc).permute(1, 0, 2).contiguous()
+
+    def cols_lpdf_vjp_owned(self, spec_cols, cov_cols, cov_nyquist, height, width, col0, need_cov_grad=True):
+        nc = spec_cols.shape[1]
+        cov = torch.full((height, width // 2 + 1), float("nan"), dtype=torch.float64)  # only the owned columns are valid
+        cov[:, col0:col0 + nc] = cov_cols
+        if col0 == 0:
+            cov[:, width // 2] = cov_nyquist
+        out = torch.full_like(cov, float("nan")) if need_cov_grad else None
+        lp, mn = self.cols_lpdf_vjp(spec_cols, cov, out, height, width, col0)
+        if not need_cov_grad:
+            return lp, mn, None, None
+        return lp, mn, out[:, col0:col0 + nc].contiguous(), (out[:, width // 2].contiguous() if col0 == 0 else None)
+
+    def rows_inv_blocked(self, recv, height, width, alpha):
+        world, rows, nc = recv.shape
+        return self.rows_inv(recv.permute(1, 0, 2).contiguous().view(rows, world * nc), height, width, alpha)
+
     def rows_fwd(self, y_rows, loc_rows, height, width):
         f = np.fft.rfft(y_rows.numpy() - loc_rows.numpy(), axis=1)
         spec = f[:, : width // 2].copy()
