@@ -117,16 +117,35 @@ __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x -
 __device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
 __device__ __forceinline__ cplx cscale(cplx a, double s) { return make_double2(a.x * s, a.y * s); }
 
-// 64-lane wavefront reductions (DPP/shuffle based), then one LDS hop across the waves of a workgroup.
+// 64-lane wavefront reductions on the DPP data path (no LDS traffic): butterflies inside a row of 16 lanes
+// (quad_perm, row_half_mirror, row_mirror), then row_bcast15 / row_bcast31 carry the row totals up to lane 63, which
+// is read back into every lane. Then one LDS hop across the waves of a workgroup (block_sum_min).
+// `old` is what a lane keeps when the DPP source is masked out: the reduction's neutral element.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64(double old, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane63_to_all(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f64<0xB1, 0xf>(0.0, v);  // quad_perm [1, 0, 3, 2]
+    v += dpp_f64<0x4E, 0xf>(0.0, v);  // quad_perm [2, 3, 0, 1]
+    v += dpp_f64<0x141, 0xf>(0.0, v); // row_half_mirror
+    v += dpp_f64<0x140, 0xf>(0.0, v); // row_mirror: every lane of a row holds the row's sum
+    v += dpp_f64<0x142, 0xa>(0.0, v); // row_bcast15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xc>(0.0, v); // row_bcast31 into rows 2 and 3: lane 63 holds the total
+    return lane63_to_all(v);
 }
 __device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmin(v, dpp_f64<0xB1, 0xf>(INFINITY, v));
+    v = fmin(v, dpp_f64<0x4E, 0xf>(INFINITY, v));
+    v = fmin(v, dpp_f64<0x141, 0xf>(INFINITY, v));
+    v = fmin(v, dpp_f64<0x140, 0xf>(INFINITY, v));
+    v = fmin(v, dpp_f64<0x142, 0xa>(INFINITY, v));
+    v = fmin(v, dpp_f64<0x143, 0xc>(INFINITY, v));
+    return lane63_to_all(v);
 }
 // red must hold >= 2 * (blockDim.x / 64) doubles. Result valid in thread 0.
 __device__ __forceinline__ void block_sum_min(double& s, double& m, double* red) {
