@@ -189,6 +189,7 @@ struct gpt_ctx {
     int total_cus = 0;
     HostPipe* pipe = nullptr; // pinned staging ring of the host-pointer entry points (created on first large transfer)
     unsigned char* scratch = nullptr; // this device's copy of the built-in scratch array (gpt_gp_rfft2_lpdf_vjp_noalloc)
+    gpt_anyn* anyn = nullptr; // plans, tables and scratch of the any-length path (gpt_anyn.hip), created on first use
 };
 
 // Built-in scratch of the allocation-free entry point (gpt_gp_rfft2_lpdf_vjp_noalloc): twiddle tables, per-workgroup
@@ -294,6 +295,7 @@ int path_for_shape(int64_t H, int64_t W) {
     if (gpt_small_fits((int)H, (int)W, nullptr, nullptr)) return 0;
     if (gpt_pow2_supported((int)H, (int)W)) return 1;
     if (gpt_generic_supported((int)H, (int)W)) return 2;
+    if (gpt_anyn_supported((int)H, (int)W)) return 3;
     return -1;
 }
 
@@ -325,6 +327,10 @@ int run_units(gpt_ctx* c, int op, const LatArgs& a, int path, int64_t chunk, cpl
         if (s.min_eig) s.min_eig += b0;
         if (s.kpar) s.kpar += b0 * 5;
         if (s.ksums) s.ksums += b0 * 4;
+        if (path == 3) {
+            HIP_TRY(c, gpt_launch_anyn(c->anyn, op, s, c->stream));
+            continue;
+        }
         if (path != 1) {
             HIP_TRY(c, gpt_launch_generic(op, s, ws, partials, c->stream));
             continue;
@@ -352,9 +358,13 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (a.batch == 0) return GPT_OK;
     int rc;
+    const int path = path_for_shape(a.H, a.W);
+    if (path == 3) { // any-length path: its own plans (four-step / Bluestein), tables and scratch
+        if (!c->anyn) c->anyn = gpt_anyn_create();
+        return run_units(c, op, a, path, gpt_anyn_chunk(a.H, a.W), nullptr, nullptr, false);
+    }
     if ((rc = make_plan(c, a.W, a.pw)) != GPT_OK) return rc;
     if ((rc = make_plan(c, a.H, a.ph)) != GPT_OK) return rc;
-    const int path = path_for_shape(a.H, a.W);
     if (path == 0) {
         HIP_TRY(c, gpt_launch_small(op, a, c->stream));
         return GPT_OK;
@@ -593,6 +603,7 @@ int gpt_destroy(gpt_ctx* c) {
         c->pipe->destroy();
         delete c->pipe;
     }
+    gpt_anyn_destroy(c->anyn);
     delete c;
     return GPT_OK;
 }
@@ -1003,6 +1014,7 @@ int gpt_gp_rfft2_lpdf_vjp_noalloc(gpt_ctx* c, const double* y, int64_t y_bs, con
     };
     const char* too_big = "this lattice needs more than the 40 MiB of built-in scratch of the allocation-free entry point "
                           "(three-pass lattices up to 2048 x 2048); use gpt_gp_rfft2_lpdf_vjp";
+    if (path == 3) return fail(c, GPT_ERR_UNSUPPORTED, too_big); // (the any-length path allocates its plans and scratch)
     if ((rc = plan_radices(c, a.W, a.pw)) != GPT_OK || (rc = plan_radices(c, a.H, a.ph)) != GPT_OK) return rc;
     if ((rc = table(a.W, &a.pw.tw)) != GPT_OK) return fits ? rc : fail(c, GPT_ERR_UNSUPPORTED, too_big);
     if (a.H == a.W) a.ph.tw = a.pw.tw;

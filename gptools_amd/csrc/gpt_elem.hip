@@ -266,12 +266,14 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* partials, i
 
 // Tiled transpose through LDS: in is [batch][R][C], out is [batch][C][R]; T = 8- or 16-byte elements.
 template <typename T>
-__global__ void __launch_bounds__(256) transpose_kernel(const T* in, T* out, int R, int C) {
+__global__ void __launch_bounds__(256) transpose_kernel(const T* in, T* out, int R, int C, int nbx) {
     __shared__ T tile[32][33];
-    const int64_t b = blockIdx.z;
+    const int64_t b = blockIdx.y;
     const T* ib = in + b * (int64_t)R * C;
     T* ob = out + b * (int64_t)R * C;
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    // (tiles numbered along grid.x alone: a matrix of millions of rows has more row tiles than grid.y allows)
+    const int by = blockIdx.x / nbx, bx = blockIdx.x - by * nbx;
+    const int c0 = bx * 32, r0 = by * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
     for (int k = ty; k < 32; k += 8) {
         const int r = r0 + k, c = c0 + tx;
@@ -348,11 +350,15 @@ hipError_t gpt_launch_finalize(const double* partials, int nblk, int64_t batch, 
 
 hipError_t gpt_launch_transpose(const void* in, void* out, int R, int C, int64_t batch, int esz, hipStream_t st) {
     if (batch <= 0 || R <= 0 || C <= 0) return hipSuccess;
-    dim3 grid((C + 31) / 32, (R + 31) / 32, (unsigned)batch), block(256);
+    if (batch > 65535) return hipErrorInvalidValue; // callers chunk the batch
+    const int nbx = (C + 31) / 32;
+    const int64_t tiles = (int64_t)nbx * ((R + 31) / 32);
+    if (tiles > 2147483647LL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)tiles, (unsigned)batch), block(256);
     if (esz == 8)
-        hipLaunchKernelGGL(transpose_kernel<double>, grid, block, 0, st, (const double*)in, (double*)out, R, C);
+        hipLaunchKernelGGL(transpose_kernel<double>, grid, block, 0, st, (const double*)in, (double*)out, R, C, nbx);
     else if (esz == 16)
-        hipLaunchKernelGGL(transpose_kernel<cplx>, grid, block, 0, st, (const cplx*)in, (cplx*)out, R, C);
+        hipLaunchKernelGGL(transpose_kernel<cplx>, grid, block, 0, st, (const cplx*)in, (cplx*)out, R, C, nbx);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -52,6 +52,15 @@ size_t gpt_generic_workspace_bytes(int H, int W);
 int gpt_generic_col_blocks(int H, int W);
 hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partials, hipStream_t st);
 
+// --- any-length path (gpt_anyn.hip): axes no other path takes (long 1-D series, long non-power-of-two axes), lines of up
+// to 2^23 points by four-step and Bluestein transforms; owns its plans, tables and scratch
+struct gpt_anyn;
+bool gpt_anyn_supported(int H, int W);
+int64_t gpt_anyn_chunk(int H, int W); // most lattices one gpt_launch_anyn call takes
+gpt_anyn* gpt_anyn_create();
+void gpt_anyn_destroy(gpt_anyn* s);
+hipError_t gpt_launch_anyn(gpt_anyn* s, int op, const LatArgs& a, hipStream_t st);
+
 // --- elementwise / reduction kernels (gpt_elem.hip)
 struct ElemArgs {
     int H, W, dim1;

@@ -99,7 +99,8 @@ def close_contexts():
 
 
 def path_for_shape(height: int, width: int) -> int:
-    """0 small (one workgroup per lattice), 1 power-of-two three-pass, 2 generic three-pass, -1 none."""
+    """0 small (one workgroup per lattice), 1 power-of-two three-pass, 2 generic three-pass, 3 any-length (four-step /
+    Bluestein line transforms), -1 none."""
     return _lib.load().gpt_path_for_shape(height, width)
 
 
