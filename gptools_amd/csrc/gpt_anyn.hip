@@ -614,6 +614,12 @@ bool gpt_anyn_supported(int H, int W) {
     return H >= 1 && W >= 2 && (int64_t)H * W <= 2147483647LL && axis_ok(H) && axis_ok(W);
 }
 
+// An axis with a large prime factor costs the LDS Stockham routine of the generic path O(n p) per line; Bluestein here
+// costs O(n log n): such shapes come to this path even when their lines would fit a workgroup.
+bool gpt_anyn_preferred(int H, int W) {
+    return gpt_anyn_supported(H, W) && (largest_prime_factor(H) > A_SMOOTH || largest_prime_factor(W) > A_SMOOTH);
+}
+
 int64_t gpt_anyn_chunk(int H, int W) { // lattices per call of gpt_launch_anyn
     const int64_t NC = 1 + (W - 1) / 2, Hp = (H + 1) / 2;
     const int64_t per = Hp * W > NC * H ? Hp * W : NC * H;

@@ -294,7 +294,7 @@ int path_for_shape(int64_t H, int64_t W) {
     if (H < 1 || W < 1 || H * W > 2147483647LL) return -1;
     if (gpt_small_fits((int)H, (int)W, nullptr, nullptr)) return 0;
     if (gpt_pow2_supported((int)H, (int)W)) return 1;
-    if (gpt_generic_supported((int)H, (int)W)) return 2;
+    if (gpt_generic_supported((int)H, (int)W) && !gpt_anyn_preferred((int)H, (int)W)) return 2;
     if (gpt_anyn_supported((int)H, (int)W)) return 3;
     return -1;
 }

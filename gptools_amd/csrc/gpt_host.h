@@ -56,6 +56,7 @@ hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partia
 // to 2^23 points by four-step and Bluestein transforms; owns its plans, tables and scratch
 struct gpt_anyn;
 bool gpt_anyn_supported(int H, int W);
+bool gpt_anyn_preferred(int H, int W); // ... and an axis has a prime factor > 127 (Bluestein beats the O(n p) Stockham stage)
 int64_t gpt_anyn_chunk(int H, int W); // most lattices one gpt_launch_anyn call takes
 gpt_anyn* gpt_anyn_create();
 void gpt_anyn_destroy(gpt_anyn* s);

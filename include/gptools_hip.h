@@ -11,7 +11,8 @@
  *   - the 1-D functions are the 2-D ones with height == 1 and the 1-D packing layout of fft1.stan:44-51;
  *   - gpt_*        : every pointer is a DEVICE pointer, arrays are row-major (NumPy / torch order), the
  *                    call is asynchronous on the context's stream and never allocates in the steady
- *                    state (workspaces are cached in the context). `*_bs` arguments are batch strides in
+ *                    state (workspaces, plans and tables are cached in the context; the first call on a
+ *                    new shape may allocate and synchronise). `*_bs` arguments are batch strides in
  *                    elements; 0 broadcasts one array over the batch. Output arrays are dense
  *                    ([batch][height][width] etc.).
  *   - gpt_*_host   : every pointer is a HOST pointer; the library stages H2D/D2H, synchronises, and
@@ -69,7 +70,8 @@ const char* gpt_version(void);
 int gpt_profile_begin(gpt_ctx* ctx);
 int gpt_profile_end(gpt_ctx* ctx, double* pass_ms, int64_t* launches);
 /* Which kernel family a lattice shape runs on: 0 small (one workgroup per lattice, any H/W),
- * 1 power-of-two three-pass, 2 generic three-pass, -1 unsupported. */
+ * 1 power-of-two three-pass, 2 generic three-pass, 3 any-length (axes of up to 2^23 points by four-step and
+ * Bluestein line transforms: long 1-D series, util.stan:263-265 takes any n), -1 unsupported. */
 int gpt_path_for_shape(int64_t height, int64_t width);
 
 /* ---- slab decomposition: ONE lattice over several GPUs (no counterpart in the reference, which

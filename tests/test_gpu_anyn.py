@@ -74,7 +74,8 @@ def test_long_series_vs_oracle(fft, n):
 
 
 SHAPES_2D = [(5000, 6), (6, 5000), (4099, 8), (8, 8186), (4100, 300), (16384, 32), (32, 32768), (3, 10007), (5003, 5),
-             (6000, 4500)]
+             (6000, 4500),
+             (2053, 12), (10, 4093), (1031, 1033)]  # lines that fit a workgroup but have a large prime factor: Bluestein
 
 
 @pytest.mark.parametrize("shape", SHAPES_2D, ids=lambda s: f"{s[0]}x{s[1]}")
