@@ -10,8 +10,8 @@ the W/2 + 1 frequencies split evenly). One evaluation:
     inverse column FFT)  ->  all-to-all  ->  rows inverse (local)  ;  all-reduce(sum) lpdf, all-reduce(min)
 
 The local passes are the HIP kernels of the single-GPU path (C ABI `gpt_slab_*`); the exchanges are
-`torch.distributed.all_to_all_single` (RCCL over xGMI with the nccl backend; gloo in the CPU tests, where the
-tests plug in their own local passes). Nothing is replicated and nothing is copied between layouts: the row kernels
+`torch.distributed` all-to-alls (RCCL over xGMI with the nccl backend; gloo in the CPU tests, where the tests plug in
+their own local passes), issued per chunk of rows and asynchronously, so that they overlap the row transforms. Nothing is replicated and nothing is copied between layouts: the row kernels
 write / read the all-to-all's own (rank, rows, columns) buffers, and a rank holds only its W/(2G) columns of `cov` /
 `d/dcov` (`gp_rfft2_lpdf_vjp_slab_owned`; rank 0 also holds column W/2, which travels with packed column 0).
 
@@ -63,9 +63,10 @@ class HipStages:
             out_nyq = edge[3].clone()
         return lp, mn, out_cols, out_nyq
 
-    def rows_inv_blocked(self, recv, height, width, alpha):
+    def rows_inv_blocked(self, recv, height, width, alpha, out=None):
         world, rows, nc = recv.shape
-        out = torch.empty(rows, width, dtype=torch.float64, device=recv.device)
+        if out is None:
+            out = torch.empty(rows, width, dtype=torch.float64, device=recv.device)
         ctx = _fft.get_context(recv.device)
         ctx.call("gpt_slab_rows_inv_blocked", _fft._p(recv), nc, rows, height, width, float(alpha), _fft._p(out))
         return out
@@ -111,6 +112,13 @@ class HipStages:
         return lp, out, mn
 
 
+class _Done:
+    """Handle of an exchange that has already completed."""
+
+    def wait(self):
+        return None
+
+
 class DistComm:
     """Exchanges over a torch.distributed process group (nccl = RCCL on the GPUs, gloo on CPU)."""
 
@@ -132,6 +140,19 @@ class DistComm:
         self.dist.all_to_all_single(out, real, group=self.group)
         return torch.view_as_complex(out)
 
+    def all_to_all_start(self, send_parts, recv_parts):
+        """Asynchronous exchange of one chunk: send_parts[p] goes to rank p, recv_parts[p] is filled from rank p; every
+        part is a contiguous tensor (views into larger buffers are fine). Returns a handle; wait() orders the current
+        stream behind the exchange. With RCCL the transfer runs on the communicator's own stream, behind what the
+        current stream has queued so far, so kernels launched after this call overlap it."""
+        if self.dist.get_backend(self.group) == "nccl":
+            return self.dist.all_to_all([torch.view_as_real(t) for t in recv_parts],
+                                        [torch.view_as_real(t) for t in send_parts], group=self.group, async_op=True)
+        got = self.all_to_all(torch.stack(list(send_parts)))  # gloo (CPU tests, rehearsals): synchronous
+        for dst, src in zip(recv_parts, got):
+            dst.copy_(src)
+        return _Done()
+
     def all_reduce_sum(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
@@ -148,6 +169,10 @@ class SingleComm:
 
     def all_to_all(self, send):
         return send
+
+    def all_to_all_start(self, send_parts, recv_parts):
+        recv_parts[0].copy_(send_parts[0])
+        return _Done()
 
     def all_reduce_sum(self, t):
         return t
@@ -182,6 +207,20 @@ class ThreadComm:
     def all_to_all(self, send):
         return torch.stack([blk[self.rank] for blk in self._exchange(send)])
 
+    def all_to_all_start(self, send_parts, recv_parts):
+        s = self.shared
+        cuda = send_parts[0].is_cuda
+        if cuda:
+            torch.cuda.current_stream(send_parts[0].device).synchronize()
+        s.slots[self.rank] = list(send_parts)
+        s.barrier.wait()
+        for dst, parts in zip(recv_parts, list(s.slots)):
+            dst.copy_(parts[self.rank])
+        if cuda:
+            torch.cuda.current_stream(send_parts[0].device).synchronize()
+        s.barrier.wait()  # (everyone has copied: the slots and the send buffers may be reused)
+        return _Done()
+
     def all_reduce_sum(self, t):
         return torch.stack(self._exchange(t)).sum(dim=0)
 
@@ -206,8 +245,18 @@ def own_columns(cov_rfft2, rank, world):
     return cols, (cov_rfft2[:, wf - 1].contiguous() if rank == 0 else None)
 
 
+def exchange_chunks(rows, world, chunks=None):
+    """Row chunks per exchange: the requested number, or 4 when there are peers to overlap with; reduced until every
+    chunk is an even number of rows (the row kernels transform rows in pairs)."""
+    c = (4 if world > 1 else 1) if chunks is None else int(chunks)
+    c = max(1, min(c, rows // 2))
+    while c > 1 and (rows % c or (rows // c) % 2):
+        c -= 1
+    return c
+
+
 def gp_rfft2_lpdf_vjp_slab_owned(y_rows, loc_rows, cov_cols, cov_nyquist, height, width, comm=None, stages=None,
-                                 need_cov_grad=True):
+                                 need_cov_grad=True, chunks=None):
     """Value and gradients of `gp_rfft2_lpdf` (fft2.stan:189-192) for one lattice split over `comm.world` ranks, every
     array in the layout its owner needs and nothing replicated.
 
@@ -215,7 +264,12 @@ def gp_rfft2_lpdf_vjp_slab_owned(y_rows, loc_rows, cov_cols, cov_nyquist, height
     (H, W / (2 G)) (`own_columns`); cov_nyquist: column W/2, (H,), on rank 0, None elsewhere. Returns (lpdf, d/dy of this
     rank's rows, min over the lattice of n c / 2, d/dcov of this rank's columns, d/dcov of column W/2 on rank 0);
     d/dloc = -d/dy; lpdf and the minimum are identical on all ranks. The row passes write and read the all-to-all's own
-    (G, rows, columns) buffers: no layout copies on either side of the two exchanges."""
+    (G, rows, columns) buffers: no layout copies on either side of the two exchanges.
+
+    The rank's rows are cut into `chunks` groups (default 4 with peers, `exchange_chunks`), each with its own
+    asynchronous all-to-all: the exchange of chunk k travels while the row transforms of chunk k + 1 run (forward), and
+    the inverse row transforms of chunk k run while chunk k + 1 travels (inverse). Only the column pass waits for
+    everything: it needs every row of its columns."""
     comm = comm or SingleComm()
     stages = stages or HipStages()
     world, rank = comm.world, comm.rank
@@ -225,18 +279,46 @@ def gp_rfft2_lpdf_vjp_slab_owned(y_rows, loc_rows, cov_cols, cov_nyquist, height
     if tuple(cov_cols.shape) != (height, nc) or (rank == 0) != (cov_nyquist is not None):
         raise ValueError(f"rank {rank} must pass its {height} x {nc} columns of cov (rank 0: and column W/2)")
     n = height * width
-    send = stages.rows_fwd_blocked(y_rows.contiguous(), loc_rows.contiguous(), height, width, world)  # (G, rows, nc)
-    cols = comm.all_to_all(send).reshape(height, nc)                                      # all rows, my columns
+    nchunk = exchange_chunks(rows, world, chunks)
+    y_rows, loc_rows = y_rows.contiguous(), loc_rows.contiguous()
+    if nchunk == 1:
+        send = stages.rows_fwd_blocked(y_rows, loc_rows, height, width, world)            # (G, rows, nc)
+        cols = comm.all_to_all(send).reshape(height, nc)                                  # all rows, my columns
+    else:
+        rc = rows // nchunk
+        cols = torch.empty(height, nc, dtype=torch.complex128, device=y_rows.device)
+        cols3 = cols.view(world, rows, nc)                                                # block p: rank p's rows
+        pending = []
+        for k in range(nchunk):
+            r0 = k * rc
+            send = stages.rows_fwd_blocked(y_rows[r0:r0 + rc], loc_rows[r0:r0 + rc], height, width, world)  # (G, rc, nc)
+            work = comm.all_to_all_start(list(send.unbind(0)), [cols3[p, r0:r0 + rc] for p in range(world)])
+            pending.append((work, send))                                                  # (send stays alive until waited for)
+        for work, _ in pending:
+            work.wait()
     lp, mn, dcov_cols, dcov_nyq = stages.cols_lpdf_vjp_owned(cols, cov_cols.contiguous(), cov_nyquist, height, width,
                                                              rank * nc, need_cov_grad)
-    back = comm.all_to_all(cols.view(world, rows, nc))                                    # (G, rows, nc): my rows
-    grad_rows = stages.rows_inv_blocked(back, height, width, -1.0 / n)
+    if nchunk == 1:
+        back = comm.all_to_all(cols.view(world, rows, nc))                                # (G, rows, nc): my rows
+        grad_rows = stages.rows_inv_blocked(back, height, width, -1.0 / n)
+    else:
+        cols3 = cols.view(world, rows, nc)
+        grad_rows = torch.empty(rows, width, dtype=torch.float64, device=y_rows.device)
+        pending = []
+        for k in range(nchunk):
+            r0 = k * rc
+            back = torch.empty(world, rc, nc, dtype=torch.complex128, device=y_rows.device)
+            work = comm.all_to_all_start([cols3[p, r0:r0 + rc] for p in range(world)], list(back.unbind(0)))
+            pending.append((work, back))
+        for k, (work, back) in enumerate(pending):
+            work.wait()
+            stages.rows_inv_blocked(back, height, width, -1.0 / n, out=grad_rows[k * rc:(k + 1) * rc])
     lp = comm.all_reduce_sum(lp.clone()) - 0.5 * n * math.log(2.0 * math.pi)
     mn = comm.all_reduce_min(mn.clone())
     return lp.reshape(()), grad_rows, mn.reshape(()), dcov_cols, dcov_nyq
 
 
-def gp_rfft2_lpdf_vjp_slab(y_rows, loc_rows, cov_rfft2, height, width, comm=None, stages=None, out_cov=None):
+def gp_rfft2_lpdf_vjp_slab(y_rows, loc_rows, cov_rfft2, height, width, comm=None, stages=None, out_cov=None, chunks=None):
     """`gp_rfft2_lpdf_vjp_slab_owned` for callers that hold the whole (H, W/2 + 1) spectrum on every rank: the rank's
     columns are cut out of `cov_rfft2` and, if `out_cov` (H, W/2+1) is given, d/dcov is written back into this rank's
     columns of it. Returns (lpdf, d/dy of this rank's rows, min over the lattice of n c / 2)."""
@@ -254,7 +336,7 @@ def gp_rfft2_lpdf_vjp_slab(y_rows, loc_rows, cov_rfft2, height, width, comm=None
     cov_cols, cov_nyq = own_columns(cov_rfft2, rank, world)
     lp, grad_rows, mn, dcols, dnyq = gp_rfft2_lpdf_vjp_slab_owned(y_rows, loc_rows, cov_cols, cov_nyq, height, width,
                                                                   comm=comm, stages=stages,
-                                                                  need_cov_grad=out_cov is not None)
+                                                                  need_cov_grad=out_cov is not None, chunks=chunks)
     if out_cov is not None:
         out_cov[:, rank * nc:(rank + 1) * nc] = dcols
         if rank == 0:

@@ -29,9 +29,13 @@ class NumpyStages:
             return lp, mn, None, None
         return lp, mn, out[:, col0:col0 + nc].contiguous(), (out[:, width // 2].contiguous() if col0 == 0 else None)
 
-    def rows_inv_blocked(self, recv, height, width, alpha):
+    def rows_inv_blocked(self, recv, height, width, alpha, out=None):
         world, rows, nc = recv.shape
-        return self.rows_inv(recv.permute(1, 0, 2).contiguous().view(rows, world * nc), height, width, alpha)
+        res = self.rows_inv(recv.permute(1, 0, 2).contiguous().view(rows, world * nc), height, width, alpha)
+        if out is None:
+            return res
+        out.copy_(res)
+        return out
 
     def rows_fwd(self, y_rows, loc_rows, height, width):
         f = np.fft.rfft(y_rows.numpy() - loc_rows.numpy(), axis=1)

@@ -35,7 +35,7 @@ def _inputs(h, w):
     return rng.normal(size=(h, w)), rng.normal(size=(h, w)), cov
 
 
-def _worker(rank, world, port, h, w, q):
+def _worker(rank, world, port, h, w, q, chunks=None):
     import torch.distributed as dist
     from slab_stages_np import NumpyStages
 
@@ -49,21 +49,23 @@ def _worker(rank, world, port, h, w, q):
         out_cov = torch.full((h, w // 2 + 1), np.nan, dtype=torch.float64)
         lp, gy, mn = slab.gp_rfft2_lpdf_vjp_slab(torch.from_numpy(y[sl].copy()), torch.from_numpy(loc[sl].copy()),
                                                  torch.from_numpy(cov), h, w, comm=slab.DistComm(),
-                                                 stages=NumpyStages(), out_cov=out_cov)
+                                                 stages=NumpyStages(), out_cov=out_cov, chunks=chunks)
         dist.barrier()
         q.put((rank, float(lp), gy.numpy(), float(mn), out_cov.numpy()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h,w", [(2, 8, 8), (2, 12, 20), (4, 16, 24)])
-def test_slab_protocol_matches_oracle(world, h, w):
+# chunks: None = the default (up to 4 row chunks per exchange, each its own asynchronous all-to-all), 1 = one exchange
+@pytest.mark.parametrize("world,h,w,chunks", [(2, 8, 8, None), (2, 12, 20, None), (4, 16, 24, None), (2, 12, 20, 1),
+                                              (2, 32, 16, 4)])
+def test_slab_protocol_matches_oracle(world, h, w, chunks):
     import gp_oracle as oracle
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
@@ -103,3 +105,13 @@ def test_slab_single_rank_and_shape_errors():
     with pytest.raises(ValueError):
         slab.gp_rfft2_lpdf_vjp_slab(torch.from_numpy(y[:2]), torch.from_numpy(loc), torch.from_numpy(cov), h, w,
                                     stages=NumpyStages())
+
+
+def test_exchange_chunks():
+    assert slab.exchange_chunks(512, 8) == 4          # default with peers
+    assert slab.exchange_chunks(512, 1) == 1          # nothing to overlap with
+    assert slab.exchange_chunks(6, 2) == 3            # 4 does not divide 6 rows into even chunks
+    assert slab.exchange_chunks(4, 4) == 2
+    assert slab.exchange_chunks(2, 2) == 1
+    assert slab.exchange_chunks(4096, 8, chunks=16) == 16
+    assert slab.exchange_chunks(10, 2, chunks=4) == 1  # 10 rows: only one even chunk works (5 is odd)
