@@ -537,15 +537,22 @@ hipError_t get_axis(gpt_anyn* s, int n, const Axis** out, hipStream_t st) {
         ax.pn1 = 1;
         ax.pn2 = n;
         void *c = nullptr, *b = nullptr;
-        A_TRY(hipMalloc(&c, sizeof(cplx) * (size_t)n));
-        A_TRY(hipMalloc(&b, sizeof(cplx) * (size_t)M));
-        hipLaunchKernelGGL(blue_chirp_kernel, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<cplx*>(c), n);
-        A_TRY(hipGetLastError());
-        hipLaunchKernelGGL(blue_filter_kernel, dim3((M + 255) / 256), dim3(256), 0, st, reinterpret_cast<cplx*>(b),
-                           reinterpret_cast<const cplx*>(c), n, M);
-        A_TRY(hipGetLastError());
-        A_TRY(fft_run(ax.f, reinterpret_cast<cplx*>(b), 1, false, st));
-        A_TRY(hipStreamSynchronize(st));
+        auto tables = [&]() -> hipError_t {
+            A_TRY(hipMalloc(&c, sizeof(cplx) * (size_t)n));
+            A_TRY(hipMalloc(&b, sizeof(cplx) * (size_t)M));
+            hipLaunchKernelGGL(blue_chirp_kernel, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<cplx*>(c), n);
+            A_TRY(hipGetLastError());
+            hipLaunchKernelGGL(blue_filter_kernel, dim3((M + 255) / 256), dim3(256), 0, st, reinterpret_cast<cplx*>(b),
+                               reinterpret_cast<const cplx*>(c), n, M);
+            A_TRY(hipGetLastError());
+            A_TRY(fft_run(ax.f, reinterpret_cast<cplx*>(b), 1, false, st));
+            return hipStreamSynchronize(st);
+        };
+        if (const hipError_t e = tables(); e != hipSuccess) {
+            if (c) (void)hipFree(c);
+            if (b) (void)hipFree(b);
+            return e;
+        }
         ax.chirp = reinterpret_cast<const cplx*>(c);
         ax.bhat = reinterpret_cast<const cplx*>(b);
     }

@@ -35,6 +35,13 @@ def test_path_selection_needs_no_gpu():
     assert lib.gpt_path_for_shape(1, 128) == 0
     assert lib.gpt_path_for_shape(0, 5) == -1
     assert lib.gpt_path_for_shape(65536, 65536) == -1  # n exceeds the reference's 32-bit int
+    # any-length path: long series, long or prime axes (four-step / Bluestein line transforms)
+    assert lib.gpt_path_for_shape(1, 8192) == 3 and lib.gpt_path_for_shape(1, 10007) == 3
+    assert lib.gpt_path_for_shape(5000, 6) == 3 and lib.gpt_path_for_shape(16384, 16384) == 3
+    assert lib.gpt_path_for_shape(10, 4093) == 3  # fits the generic path's lines, but 4093 is prime: Bluestein
+    assert lib.gpt_path_for_shape(110, 110) == 2 and lib.gpt_path_for_shape(4096, 4096) == 1
+    assert lib.gpt_path_for_shape(1, 1 << 24) == 3  # 4096 x 4096: the longest four-step line
+    assert lib.gpt_path_for_shape(1, (1 << 23) + 1) == -1  # would need a Bluestein transform of 2^25 points
 
 
 def test_product_path_does_not_import_the_oracle():
