@@ -478,6 +478,9 @@ hipError_t raise_lds(gpt_anyn* s) {
 
 hipError_t lines_fft(const LinePlan& p, cplx* data, int64_t nlines, bool inv, hipStream_t st) {
     if (p.n <= 1 || nlines <= 0) return hipSuccess;
+    // power-of-two lines of 256 ... 4096 points: the register-tile kernel of the tuned path (bandwidth-bound, 3x the
+    // LDS Stockham routine below)
+    if (gpt_pow2_line_fft_supported(p.n)) return gpt_pow2_line_fft(p.n, inv, data, nlines, p.tw, st);
     const int LP = A_BUF / p.n > 1 ? A_BUF / p.n : 1;
     const dim3 grid((unsigned)((nlines + LP - 1) / LP));
     const size_t lds = 2 * (size_t)A_BUF * sizeof(cplx);

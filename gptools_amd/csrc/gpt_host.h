@@ -46,6 +46,10 @@ int gpt_pow2_obs_blocks(int H, int W);
 hipError_t gpt_pow2_obs_rows(const LatArgs& a, cplx* ws, double* partials, int col_cus, const ObsRowArgs& o,
                              hipStream_t st);
 
+// Contiguous complex lines of n = 256 ... 4096 points (power of two), in place, with the register-tile kernels.
+bool gpt_pow2_line_fft_supported(int n);
+hipError_t gpt_pow2_line_fft(int n, bool inverse, cplx* data, int64_t nlines, const cplx* tw, hipStream_t st);
+
 // --- generic large path (gpt_generic.hip): any H, W whose lines fit LDS
 bool gpt_generic_supported(int H, int W);
 size_t gpt_generic_workspace_bytes(int H, int W);

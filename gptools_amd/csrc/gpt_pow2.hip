@@ -303,3 +303,11 @@ hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, in
     }
     return hipErrorInvalidValue;
 }
+
+// Register-tile transform of `nlines` contiguous complex lines of n = 256 ... 4096 points (a power of two), in place,
+// unnormalised; tw = w_n^m table. For the paths that compose long lines from short ones (gpt_anyn.hip).
+bool gpt_pow2_line_fft_supported(int n) { return n >= 256 && n <= 4096 && (n & (n - 1)) == 0; }
+hipError_t gpt_pow2_line_fft(int n, bool inverse, cplx* data, int64_t nlines, const cplx* tw, hipStream_t st) {
+    if (!gpt_pow2_line_fft_supported(n)) return hipErrorInvalidValue;
+    return sub_by_size(n, [&](auto l) { return decltype(l)::line_fft(inverse, data, nlines, tw, st); });
+}

@@ -33,7 +33,10 @@ def main():
              ("2-D 6000 x 4500 (four-step rows and columns), 1 lattice", (6000, 4500), 1),
              ("2-D 5003 x 5003 (prime: Bluestein on 16384 both ways), 1 lattice", (5003, 5003), 1),
              ("2-D 16384 x 16384 (four-step 4 x 4096 both ways), 1 lattice", (16384, 16384), 1)]
+    only = sys.argv[1] if len(sys.argv) > 1 else ""  # substring of the case label
     for label, shape, batch in cases:
+        if only not in label:
+            continue
         if len(shape) == 1:
             n = shape[0]
             cov = oracle.gp_periodic_matern_cov_rfft(1.5, n, 1.2, n / 10.0, float(n)) + 1e-3
