@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPT_LIB: another build of the same library (tuning variants made by scripts/mkvar.sh)
 LIB_PATH = os.environ.get("GPT_LIB") or os.path.join(_HERE, "libgptools_hip.so")
 
-GPT_OK, GPT_ERR_NOT_PD, GPT_ERR_SHAPE, GPT_ERR_UNSUPPORTED = 0, 1, 2, 3
+GPT_OK, GPT_ERR_NOT_PD, GPT_ERR_SHAPE, GPT_ERR_UNSUPPORTED, GPT_ERR_TIMEOUT = 0, 1, 2, 3, 4
 GPT_ROW_MAJOR, GPT_COL_MAJOR = 0, 1
 
 c_i64 = ctypes.c_int64
@@ -90,6 +90,7 @@ _PLAIN = {
     "gpt_batcher_destroy": ([c_ptr], c_int),
     "gpt_batcher_lpdf_host": ([c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr], c_int),
     "gpt_batcher_leave": ([c_ptr, c_int], c_int),
+    "gpt_batcher_set_timeout": ([c_ptr, c_dbl], c_int),
     "gpt_batcher_min_eig": ([c_ptr, c_int], c_dbl),
     "gpt_batcher_launches": ([c_ptr], ctypes.c_longlong),
     "gpt_batcher_last_error": ([c_ptr], ctypes.c_char_p),

@@ -19,9 +19,12 @@ def _ptr(a):
 
 
 class Batcher:
-    """``nslots`` chains, one lattice shape. ``width`` alone selects the 1-D functions (fft1.stan)."""
+    """``nslots`` chains, one lattice shape. ``width`` alone selects the 1-D functions (fft1.stan). ``timeout``
+    (seconds, 0 = none): a call that waits longer for the other chains raises TimeoutError instead of blocking for ever
+    behind a chain that ended without ``leave``."""
 
-    def __init__(self, nslots: int, height: int | None, width: int, device: int = 0, col_major: bool = False):
+    def __init__(self, nslots: int, height: int | None, width: int, device: int = 0, col_major: bool = False,
+                 timeout: float = 0.0):
         self.lib = _lib.load()
         self.dim1 = height is None
         self.shape = (width,) if self.dim1 else (height, width)
@@ -34,6 +37,8 @@ class Batcher:
         if rc != 0:
             raise (ValueError if rc == _lib.GPT_ERR_SHAPE else RuntimeError)(f"gpt_batcher_create failed ({rc})")
         self.handle = h
+        if timeout:
+            self.lib.gpt_batcher_set_timeout(h, float(timeout))
 
     def _arr(self, x, shape):
         x = np.asarray(x, dtype=np.float64)
@@ -56,6 +61,8 @@ class Batcher:
             raise NotPositiveDefinite(f"covariance matrix is not positive-definite (minimum eigenvalue is {mn})")
         if rc == _lib.GPT_ERR_SHAPE:
             raise ValueError(f"slot {slot} is out of range or has left the batcher")
+        if rc == _lib.GPT_ERR_TIMEOUT:
+            raise TimeoutError(self.lib.gpt_batcher_last_error(self.handle).decode())
         if rc != 0:
             raise RuntimeError(f"batched evaluation failed ({rc}): {self.lib.gpt_batcher_last_error(self.handle).decode()}")
         return (lp.value, gy, gc) if grad else lp.value

@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -35,6 +36,7 @@ struct gpt_batcher {
     unsigned long long generation = 0, launches = 0;
     int batch_rc = GPT_OK;
     std::string err;
+    double timeout_s = 0.0; // longest wait for the other chains (0: for ever), gpt_batcher_set_timeout
 };
 
 namespace {
@@ -180,8 +182,20 @@ int gpt_batcher_lpdf_host(gpt_batcher* b, int slot, const double* y, const doubl
         b->want_gy = b->want_gy || grad_y != nullptr;
         b->want_gc = b->want_gc || grad_cov != nullptr;
         const unsigned long long gen = b->generation;
-        if (++b->arrived >= b->nactive) run_batch(b);
-        else b->cv.wait(lk, [&] { return b->generation != gen; });
+        if (++b->arrived >= b->nactive) {
+            run_batch(b);
+        } else if (b->timeout_s > 0.0) {
+            const auto limit = std::chrono::duration<double>(b->timeout_s);
+            if (!b->cv.wait_for(lk, limit, [&] { return b->generation != gen; })) {
+                // a chain ended without gpt_batcher_leave: this call gives up (its slot stays active and may call again)
+                b->arrived--;
+                b->err = "timed out waiting for the other chains: " + std::to_string(b->nactive - b->arrived - 1) +
+                         " active slot(s) did not call (a chain that ends must gpt_batcher_leave its slot)";
+                return GPT_ERR_TIMEOUT;
+            }
+        } else {
+            b->cv.wait(lk, [&] { return b->generation != gen; });
+        }
         rc = b->batch_rc;
     }
     if (rc != GPT_OK) return rc;
@@ -203,6 +217,13 @@ int gpt_batcher_leave(gpt_batcher* b, int slot) {
     memset(b->h_loc + (size_t)slot * b->hw, 0, sizeof(double) * (size_t)b->hw);
     for (int64_t i = 0; i < b->hwf; ++i) b->h_cov[(size_t)slot * b->hwf + i] = 1.0;
     if (b->nactive > 0 && b->arrived >= b->nactive) run_batch(b); // the others were waiting for this chain only
+    return GPT_OK;
+}
+
+int gpt_batcher_set_timeout(gpt_batcher* b, double seconds) {
+    if (!b || !(seconds >= 0.0)) return GPT_ERR_SHAPE;
+    std::unique_lock<std::mutex> lk(b->m);
+    b->timeout_s = seconds;
     return GPT_OK;
 }
 

@@ -48,6 +48,7 @@ enum {
     GPT_ERR_NOT_PD = 1,
     GPT_ERR_SHAPE = 2,
     GPT_ERR_UNSUPPORTED = 3,
+    GPT_ERR_TIMEOUT = 4, /* gpt_batcher_lpdf_host only: the other chains did not arrive within gpt_batcher_set_timeout */
     GPT_ERR_HIP = -1,
     GPT_ERR_ALLOC = -2
 };
@@ -131,6 +132,10 @@ int gpt_batcher_destroy(gpt_batcher* b);
 int gpt_batcher_lpdf_host(gpt_batcher* b, int slot, const double* y, const double* loc, const double* cov,
                           double* lpdf, double* grad_y, double* grad_cov);
 int gpt_batcher_leave(gpt_batcher* b, int slot);
+/* Longest time a call waits for the other active chains (seconds; 0, the default: for ever). When it expires the call
+ * returns GPT_ERR_TIMEOUT, nothing has been evaluated for it, and the slot may call again -- the way out when a chain
+ * died without gpt_batcher_leave. No counterpart in the reference. */
+int gpt_batcher_set_timeout(gpt_batcher* b, double seconds);
 double gpt_batcher_min_eig(gpt_batcher* b, int slot);
 long long gpt_batcher_launches(gpt_batcher* b); /* fused launches so far */
 const char* gpt_batcher_last_error(gpt_batcher* b);

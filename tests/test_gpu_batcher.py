@@ -110,3 +110,26 @@ def test_chains_leave_and_reject():
     with pytest.raises(ValueError):
         b.lpdf(0, y[0, 0], loc, cov)  # slot 0 has left
     b.close()
+
+
+def test_timeout_when_a_chain_died_without_leaving():
+    """A chain that ends without `leave` must not block the others for ever: with a timeout the waiting call gives up
+    with TimeoutError, and once the dead chain's slot has left, the same slot evaluates normally."""
+    import gp_oracle as o
+    from gptools_amd import batch
+
+    n = 144
+    rng = np.random.default_rng(8)
+    cov = o.gp_periodic_exp_quad_cov_rfft(n, 1.1, 9.0, float(n)) + 1e-3
+    y = rng.normal(size=n)
+    b = batch.Batcher(2, None, n, timeout=0.3)
+    with pytest.raises(TimeoutError, match="did not call"):
+        b.lpdf(0, y, None, cov)  # slot 1 never calls
+    assert b.launches == 0
+    b.leave(1)
+    lp, gy, gc = b.lpdf(0, y, None, cov)
+    lp_o, gy_o, gc_o = o.gp_rfft_lpdf_vjp(y, np.zeros(n), cov)
+    _close(lp, lp_o)
+    _close(gy, gy_o)
+    _close(gc, gc_o)
+    b.close()
