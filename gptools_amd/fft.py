@@ -54,8 +54,7 @@ class Context:
         self.handle = None
 
     def sync_stream(self):
-        with torch.cuda.device(self.device):
-            cur = torch.cuda.current_stream().cuda_stream
+        cur = torch.cuda.current_stream(self.device).cuda_stream  # (no device-guard round trip: this runs on every call)
         if cur != self.stream:
             rc = self.lib.gpt_set_stream(self.handle, ctypes.c_void_p(cur))
             if rc != 0:
