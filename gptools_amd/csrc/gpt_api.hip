@@ -190,6 +190,11 @@ struct gpt_ctx {
     HostPipe* pipe = nullptr; // pinned staging ring of the host-pointer entry points (created on first large transfer)
     unsigned char* scratch = nullptr; // this device's copy of the built-in scratch array (gpt_gp_rfft2_lpdf_vjp_noalloc)
     gpt_anyn* anyn = nullptr; // plans, tables and scratch of the any-length path (gpt_anyn.hip), created on first use
+    // Pinned bounce area of the host-pointer entry points for transfers too small for the ring: arrays are packed into it
+    // so that every copy of a call is asynchronous and the call synchronises once (a pageable hipMemcpyAsync stalls the
+    // host per copy: 225 -> ~70 us per call at 64 x 64).
+    char* bounce = nullptr;
+    size_t bounce_bytes = 0;
 };
 
 // Built-in scratch of the allocation-free entry point (gpt_gp_rfft2_lpdf_vjp_noalloc): twiddle tables, per-workgroup
@@ -603,6 +608,7 @@ int gpt_destroy(gpt_ctx* c) {
         c->pipe->destroy();
         delete c->pipe;
     }
+    if (c->bounce) (void)hipHostFree(c->bounce);
     gpt_anyn_destroy(c->anyn);
     delete c;
     return GPT_OK;
@@ -1315,12 +1321,36 @@ struct Stager {
     ~Stager() {
         if (!drained) (void)hipStreamSynchronize(c->stream);
     }
+    // Small calls (the docs models: 35 x 60, n = 100 ... 200; everything up to TINY_BYTES of arena): what costs there is
+    // the number of copy <-> kernel hand-overs on the stream (~12 us each), not bytes. The bounce area mirrors the arena
+    // offset for offset, the inputs go up in ONE copy (go()), the outputs and scalars come down in ONE copy (finish()).
+    static constexpr size_t TINY_BYTES = (size_t)16 << 20; // = BOUNCE_BYTES: lattices up to 256 x 256
+    bool tiny = false, flushed = false;
+    size_t up_end = 0; // end of the uploaded part of the arena
+    struct Xpose {
+        void *t, *d;
+        int R, C, esz;
+    };
+    std::vector<Xpose> xposes; // transposes of column-major inputs, launched behind the one upload
     Stager(gpt_ctx* ctx, int lay, size_t need) : c(ctx), layout(lay) {
         if (hipSetDevice(c->device) != hipSuccess) {
             rc = fail(c, GPT_ERR_HIP, "hipSetDevice failed");
             return;
         }
         rc = ensure(c, c->arena, c->arena_bytes, need);
+        tiny = rc == GPT_OK && need <= TINY_BYTES && bounce_ready() && need <= c->bounce_bytes;
+    }
+    char* mirror(const void* dev_ptr) { return c->bounce + (static_cast<const char*>(dev_ptr) - c->arena); }
+    // after the uploads and before the first kernel of the call: returns rc
+    int go() {
+        if (rc != GPT_OK || !tiny || flushed) return rc;
+        flushed = true;
+        hipError_t e = hipSuccess;
+        if (up_end) e = hipMemcpyAsync(c->arena, c->bounce, up_end, hipMemcpyHostToDevice, c->stream);
+        for (const Xpose& x : xposes)
+            if (e == hipSuccess) e = gpt_launch_transpose(x.t, x.d, x.R, x.C, 1, x.esz, c->stream);
+        if (e != hipSuccess) rc = hip_fail(c, e, "upload");
+        return rc;
     }
     // large transfers go through the context's pinned ring (HostPipe), small ones through the runtime's pageable path
     bool piped(size_t bytes) {
@@ -1332,12 +1362,45 @@ struct Stager {
         }
         return true;
     }
+    // small transfers: a piece of the context's pinned bounce area (null: none to be had, the pageable path still works)
+    static constexpr size_t BOUNCE_BYTES = 8 * HostPipe::MIN_BYTES;
+    size_t boff = 0;
+    struct Pending {
+        void* host;
+        const char* src;
+        size_t bytes;
+    };
+    std::vector<Pending> pending; // downloads that sit in the bounce area until finish() has synchronised
+    bool bounce_ready() {
+        if (c->bounce) return true;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, BOUNCE_BYTES, hipHostMallocDefault) != hipSuccess) return false;
+        c->bounce = static_cast<char*>(p);
+        c->bounce_bytes = BOUNCE_BYTES;
+        return true;
+    }
+    char* bounce(size_t bytes) {
+        if (!bounce_ready()) return nullptr;
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (boff + need > c->bounce_bytes) return nullptr;
+        char* p = c->bounce + boff;
+        boff += need;
+        return p;
+    }
     hipError_t h2d(void* dev, const void* host, size_t bytes) {
         if (piped(bytes)) return c->pipe->up(dev, host, bytes, c->stream);
+        if (char* b = bounce(bytes)) {
+            memcpy(b, host, bytes);
+            return hipMemcpyAsync(dev, b, bytes, hipMemcpyHostToDevice, c->stream);
+        }
         return hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream);
     }
     hipError_t d2h(void* host, const void* dev, size_t bytes) {
         if (piped(bytes)) return c->pipe->down(host, dev, bytes, c->stream);
+        if (char* b = bounce(bytes)) {
+            pending.push_back({host, b, bytes});
+            return hipMemcpyAsync(b, dev, bytes, hipMemcpyDeviceToHost, c->stream);
+        }
         return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream);
     }
     void* bump(size_t bytes) {
@@ -1350,6 +1413,17 @@ struct Stager {
         if (rc != GPT_OK || !host) return nullptr;
         const size_t bytes = (size_t)R * C * esz;
         void* d = bump(bytes);
+        if (tiny) {
+            if (layout == GPT_COL_MAJOR && R > 1 && C > 1) {
+                void* t = bump(bytes);
+                memcpy(mirror(t), host, bytes);
+                xposes.push_back({t, d, (int)C, (int)R, esz});
+            } else {
+                memcpy(mirror(d), host, bytes);
+            }
+            up_end = off;
+            return d;
+        }
         hipError_t e;
         if (layout == GPT_COL_MAJOR && R > 1 && C > 1) {
             void* t = bump(bytes);
@@ -1367,6 +1441,17 @@ struct Stager {
         if (rc != GPT_OK || !host) return;
         const size_t bytes = (size_t)R * C * esz;
         hipError_t e;
+        if (tiny) { // the whole output part of the arena comes down in one copy (finish)
+            const void* src = d;
+            if (layout == GPT_COL_MAJOR && R > 1 && C > 1) {
+                void* t = bump(bytes);
+                e = gpt_launch_transpose(d, t, (int)R, (int)C, 1, esz, c->stream);
+                if (e != hipSuccess) rc = hip_fail(c, e, "download");
+                src = t;
+            }
+            pending.push_back({host, mirror(src), bytes});
+            return;
+        }
         if (layout == GPT_COL_MAJOR && R > 1 && C > 1) {
             void* t = bump(bytes);
             e = gpt_launch_transpose(d, t, (int)R, (int)C, 1, esz, c->stream);
@@ -1379,15 +1464,23 @@ struct Stager {
     int finish(double* d_min_eig) {
         if (rc != GPT_OK) return rc;
         double mn = INFINITY;
-        if (d_min_eig) {
+        if (tiny) {
+            if (off > up_end) {
+                hipError_t e = hipMemcpyAsync(c->bounce + up_end, c->arena + up_end, off - up_end, hipMemcpyDeviceToHost,
+                                              c->stream);
+                if (e != hipSuccess) return hip_fail(c, e, "download");
+            }
+        } else if (d_min_eig) {
             hipError_t e = hipMemcpyAsync(c->pinned, d_min_eig, sizeof(double), hipMemcpyDeviceToHost, c->stream);
             if (e != hipSuccess) return hip_fail(c, e, "min_eig read-back");
         }
         hipError_t e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return hip_fail(c, e, "hipStreamSynchronize");
         drained = true;
+        for (const Pending& p : pending) memcpy(p.host, p.src, p.bytes);
+        pending.clear();
         if (d_min_eig) {
-            mn = c->pinned[0];
+            mn = tiny ? *reinterpret_cast<const double*>(mirror(d_min_eig)) : c->pinned[0];
             c->last_min_eig = mn;
             if (mn < 0) {
                 char buf[128];
@@ -1419,7 +1512,7 @@ int gpt_gp_rfft2_host(gpt_ctx* c, int layout, const double* y, const double* loc
     const double* dc = (const double*)s.up(cov, H, Wf, 8);
     double* dz = (double*)s.dev(H, W, 8);
     double* dm = (double*)s.dev(1, 1, 8);
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if ((rc = gpt_gp_rfft2(c, dy, 0, dl, 0, dc, 0, H, W, 1, dim1, dz, dm))) return rc;
     s.down(z_out, dz, H, W, 8);
     return s.finish(dm);
@@ -1436,7 +1529,7 @@ int gpt_gp_inv_rfft2_host(gpt_ctx* c, int layout, const double* z, const double*
     const double* dc = (const double*)s.up(cov, H, Wf, 8);
     double* df = (double*)s.dev(H, W, 8);
     double* dm = (double*)s.dev(1, 1, 8);
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if ((rc = gpt_gp_inv_rfft2(c, dz, 0, dl, 0, dc, 0, H, W, 1, dim1, df, dm))) return rc;
     s.down(f_out, df, H, W, 8);
     return s.finish(dm);
@@ -1465,7 +1558,7 @@ int gpt_gp_inv_rfft2_obs_lpdf_host(gpt_ctx* c, int layout, int family, const dou
     double* dgz = (double*)s.dev(H, W, 8);
     double* dgc = grad_cov ? (double*)s.dev(H, Wf, 8) : nullptr;
     double* dsc = (double*)s.dev(1, 8, 8); // theta, lp, d/dloc sum, d/dtheta, min_eig
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if (dfill) {
         HIP_TRY(c, gpt_launch_fill(dfill, H * W, loc_scalar, c->stream));
         dl = dfill;
@@ -1495,7 +1588,7 @@ int gpt_gp_rfft2_log_abs_det_jac_host(gpt_ctx* c, int layout, const double* cov,
     double* dout = (double*)s.dev(1, 1, 8);
     double* dm = (double*)s.dev(1, 1, 8);
     double* dg = grad_cov ? (double*)s.dev(H, Wf, 8) : nullptr;
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if ((rc = gpt_gp_rfft2_log_abs_det_jac(c, dc, 0, H, W, 1, dim1, dout, dm))) return rc;
     if (grad_cov && (rc = gpt_gp_rfft2_log_abs_det_jac_vjp(c, dc, 0, H, W, 1, dim1, dg))) return rc;
     s.down(out, dout, 1, 1, 8);
@@ -1516,7 +1609,7 @@ int gpt_gp_rfft2_lpdf_host(gpt_ctx* c, int layout, const double* y, const double
     double* dm = (double*)s.dev(1, 1, 8);
     double* dgy = grad_y ? (double*)s.dev(H, W, 8) : nullptr;
     double* dgc = (grad_y && grad_cov) ? (double*)s.dev(H, Wf, 8) : nullptr;
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if (grad_y) rc = gpt_gp_rfft2_lpdf_vjp(c, dy, 0, dl, 0, dc, 0, H, W, 1, dim1, dlp, dgy, dgc, dm);
     else rc = gpt_gp_rfft2_lpdf(c, dy, 0, dl, 0, dc, 0, H, W, 1, dim1, dlp, dm);
     if (rc) return rc;
@@ -1537,7 +1630,7 @@ int gpt_gp_inv_rfft2_vjp_host(gpt_ctx* c, int layout, const double* z, const dou
     const double* dfb = (const double*)s.up(fbar, H, W, 8);
     double* dzb = (double*)s.dev(H, W, 8);
     double* dcb = covbar ? (double*)s.dev(H, Wf, 8) : nullptr;
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if ((rc = gpt_gp_inv_rfft2_vjp(c, dz, 0, dc, 0, dfb, 0, H, W, 1, dim1, dzb, dcb))) return rc;
     s.down(zbar, dzb, H, W, 8);
     if (covbar) s.down(covbar, dcb, H, Wf, 8);
@@ -1556,7 +1649,7 @@ int gpt_gp_rfft2_vjp_host(gpt_ctx* c, int layout, const double* y, const double*
     const double* dzb = (const double*)s.up(zbar, H, W, 8);
     double* dyb = (double*)s.dev(H, W, 8);
     double* dcb = covbar ? (double*)s.dev(H, Wf, 8) : nullptr;
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if ((rc = gpt_gp_rfft2_vjp(c, dy, 0, dl, 0, dc, 0, dzb, 0, H, W, 1, dim1, dyb, dcb))) return rc;
     s.down(ybar, dyb, H, W, 8);
     if (covbar) s.down(covbar, dcb, H, Wf, 8);
@@ -1571,7 +1664,7 @@ int gpt_rfft2_host(gpt_ctx* c, int layout, const double* y, int64_t H, int64_t W
     Stager s(c, layout, arena_need(H, W, 6));
     const double* dy = (const double*)s.up(y, H, W, 8);
     double* dout = (double*)s.dev(H, Wf, 16);
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if ((rc = gpt_rfft2(c, dy, H, W, 1, dout))) return rc;
     s.down(out_complex, dout, H, Wf, 16);
     return s.finish(nullptr);
@@ -1584,7 +1677,7 @@ int gpt_inv_rfft2_host(gpt_ctx* c, int layout, const double* z_complex, int64_t 
     Stager s(c, layout, arena_need(H, W, 8));
     const double* dz = (const double*)s.up(z_complex, H, Wf, 16);
     double* dout = (double*)s.dev(H, W, 8);
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if ((rc = gpt_inv_rfft2(c, dz, H, W, 1, dout))) return rc;
     s.down(out, dout, H, W, 8);
     return s.finish(nullptr);
@@ -1596,7 +1689,7 @@ int gpt_expand_rfft_host(gpt_ctx* c, const double* y_complex, int64_t n, double*
     Stager s(c, GPT_ROW_MAJOR, arena_need(1, n, 8));
     const double* dy = (const double*)s.up(y_complex, 1, n / 2 + 1, 16);
     double* dout = (double*)s.dev(1, n, 16);
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if ((rc = gpt_expand_rfft(c, dy, n, 1, dout))) return rc;
     s.down(out_complex, dout, 1, n, 16);
     return s.finish(nullptr);
@@ -1611,7 +1704,7 @@ int gpt_gp_evaluate_rfft2_scale_host(gpt_ctx* c, int layout, const double* cov, 
     const double* dc = (const double*)s.up(cov, H, Wf, 8);
     double* dout = (double*)s.dev(H, Wf, 8);
     double* dm = (double*)s.dev(1, 1, 8);
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if ((rc = gpt_gp_evaluate_rfft2_scale(c, dc, 0, H, W, 1, dim1, dout, dm))) return rc;
     s.down(out, dout, H, Wf, 8);
     return s.finish(dm);
@@ -1625,7 +1718,7 @@ int gpt_gp_unpack_rfft2_host(gpt_ctx* c, int layout, const double* z_complex, in
     Stager s(c, layout, arena_need(H, W, 8));
     const double* dz = (const double*)s.up(z_complex, H, Wf, 16);
     double* dout = (double*)s.dev(H, W, 8);
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if ((rc = gpt_gp_unpack_rfft2(c, dz, H, W, 1, dim1, dout))) return rc;
     s.down(out, dout, H, W, 8);
     return s.finish(nullptr);
@@ -1639,7 +1732,7 @@ int gpt_gp_pack_rfft2_host(gpt_ctx* c, int layout, const double* z, int64_t H, i
     Stager s(c, layout, arena_need(H, W, 8));
     const double* dz = (const double*)s.up(z, H, W, 8);
     double* dout = (double*)s.dev(H, Wf, 16);
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     if ((rc = gpt_gp_pack_rfft2(c, dz, H, W, 1, dim1, dout))) return rc;
     s.down(out_complex, dout, H, Wf, 16);
     return s.finish(nullptr);
@@ -1653,7 +1746,7 @@ static int spec_host(gpt_ctx* c, int layout, bool matern, double nu, int64_t H, 
     Stager s(c, layout, arena_need(H, W, 3));
     const double* dp = (const double*)s.up(params, 1, dim1 ? 3 : 5, 8);
     double* dout = (double*)s.dev(H, Wf, 8);
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     rc = matern ? gpt_gp_periodic_matern_cov_rfft2(c, nu, H, W, dp, 1, dim1, dout)
                 : gpt_gp_periodic_exp_quad_cov_rfft2(c, H, W, dp, 1, dim1, dout);
     if (rc) return rc;
@@ -1670,7 +1763,7 @@ static int spec_vjp_host(gpt_ctx* c, int layout, bool matern, double nu, int64_t
     const double* dp = (const double*)s.up(params, 1, dim1 ? 3 : 5, 8);
     const double* dcb = (const double*)s.up(covbar, H, Wf, 8);
     double* dpb = (double*)s.dev(1, 8, 8);
-    if (s.rc) return s.rc;
+    if (s.go()) return s.rc;
     rc = matern ? gpt_gp_periodic_matern_cov_rfft2_vjp(c, nu, H, W, dp, dcb, 0, 1, dim1, dpb)
                 : gpt_gp_periodic_exp_quad_cov_rfft2_vjp(c, H, W, dp, dcb, 0, 1, dim1, dpb);
     if (rc) return rc;

@@ -40,10 +40,10 @@ def main():
     n, hwf = H * W, H * wf
     for name, fn, up, down in (("gpt_gp_rfft2_lpdf_host", lpdf, 8 * (2 * n + hwf), 8 * (n + hwf)),
                                ("gpt_gp_inv_rfft2_obs_lpdf_host", obs_model, 8 * (n + hwf + oh * ow), 8 * (n + hwf))):
-        for _ in range(2):
+        for _ in range(3):
             fn()
         t0 = time.perf_counter()
-        k = 8
+        k = 8 if H * W >= 1 << 22 else 200
         for _ in range(k):
             fn()
         dt = (time.perf_counter() - t0) / k
