@@ -434,6 +434,8 @@ hipError_t line_plan(gpt_anyn* s, int n, LinePlan& p, hipStream_t st) {
         if (p.ns < GPT_MAX_STAGES) p.r[p.ns] = r;
         p.ns++;
     };
+    while (m % 16 == 0) { push(16); m /= 16; } // register butterflies: one pass through LDS for four bits
+    if (m % 8 == 0) { push(8); m /= 8; }
     while (m % 4 == 0) { push(4); m /= 4; }
     while (m % 2 == 0) { push(2); m /= 2; }
     for (int f = 3; (int64_t)f * f <= m; f += 2)

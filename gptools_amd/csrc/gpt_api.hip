@@ -272,7 +272,9 @@ int get_twiddles(gpt_ctx* c, int n, const cplx** out) {
 }
 
 // Stockham radices of a line of n points (host arithmetic only)
-int plan_radices(gpt_ctx* c, int n, LinePlan& p) {
+// wide: radix-16 / radix-8 stages first (the generic three-pass path: fewer passes through LDS); the one-workgroup
+// kernels keep radix 4 and 2 (their register budget)
+int plan_radices(gpt_ctx* c, int n, LinePlan& p, bool wide = false) {
     p.n = n;
     p.ns = 0;
     p.tw = nullptr;
@@ -281,6 +283,10 @@ int plan_radices(gpt_ctx* c, int n, LinePlan& p) {
         if (p.ns < GPT_MAX_STAGES) p.r[p.ns] = r;
         p.ns++;
     };
+    if (wide) {
+        while (m % 16 == 0) { push(16); m /= 16; }
+        if (m % 8 == 0) { push(8); m /= 8; }
+    }
     while (m % 4 == 0) { push(4); m /= 4; }
     while (m % 2 == 0) { push(2); m /= 2; }
     for (int f = 3; (int64_t)f * f <= m; f += 2)
@@ -290,8 +296,8 @@ int plan_radices(gpt_ctx* c, int n, LinePlan& p) {
     return GPT_OK;
 }
 
-int make_plan(gpt_ctx* c, int n, LinePlan& p) {
-    const int rc = plan_radices(c, n, p);
+int make_plan(gpt_ctx* c, int n, LinePlan& p, bool wide = false) {
+    const int rc = plan_radices(c, n, p, wide);
     return rc != GPT_OK ? rc : get_twiddles(c, n, &p.tw);
 }
 
@@ -368,8 +374,8 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
         if (!c->anyn) c->anyn = gpt_anyn_create();
         return run_units(c, op, a, path, gpt_anyn_chunk(a.H, a.W), nullptr, nullptr, false);
     }
-    if ((rc = make_plan(c, a.W, a.pw)) != GPT_OK) return rc;
-    if ((rc = make_plan(c, a.H, a.ph)) != GPT_OK) return rc;
+    if ((rc = make_plan(c, a.W, a.pw, path == 2)) != GPT_OK) return rc;
+    if ((rc = make_plan(c, a.H, a.ph, path == 2)) != GPT_OK) return rc;
     if (path == 0) {
         HIP_TRY(c, gpt_launch_small(op, a, c->stream));
         return GPT_OK;

@@ -23,22 +23,35 @@ struct GenGeo {
     int LP;      // row pairs per workgroup
     int TC;      // columns per workgroup
     int TCs;     // LDS stride between rows of a column tile (odd)
+    // LDS ping-pong buffers (complex elements each) and workgroup sizes of the row and the column kernels: short lines
+    // take 1024-element buffers (32 KB per workgroup, 256 threads), so that four or five workgroups share a CU and one
+    // loads while another transforms, and a launch of few lattices still fills the chip; only lines of more than 2048
+    // points need the full 4096-element buffers (128 KB: one workgroup per CU). The column kernel sizes its buffer for
+    // eight columns first: tile width (bytes per workspace row) matters more to it than occupancy (301 x 200 x 64
+    // lattices: 3-column tiles 204 us, 13-column tiles as before).
+    int rbuf, cbuf, rthreads, cthreads;
 };
+
+int buf_for_line(int n) { return n <= 1024 ? 1024 : (n <= 2048 ? 2048 : G_BUF_ELEMS); }
 
 GenGeo make_geo(int H, int W) {
     GenGeo g;
     g.NC = 1 + (W - 1) / 2;
     g.wstride = (g.NC + 7) / 8 * 8 + 8;
     g.Hp = (H + 1) / 2;
-    g.LP = G_BUF_ELEMS / W;
+    g.rbuf = buf_for_line(W);
+    g.cbuf = buf_for_line(8 * H); // at least 8 adjacent columns (whole 128-byte lines of the workspace) where LDS allows
+    g.rthreads = g.rbuf <= 1024 ? 256 : G_THREADS;
+    g.cthreads = g.cbuf <= 1024 ? 256 : G_THREADS;
+    g.LP = g.rbuf / W;
     if (g.LP < 1) g.LP = 1;
     if (g.LP > g.Hp) g.LP = g.Hp;
-    g.TC = G_BUF_ELEMS / H;
+    g.TC = g.cbuf / H;
     if (g.TC > 16) g.TC = 16;
     if (g.TC < 1) g.TC = 1;
     if (g.TC > g.NC) g.TC = g.NC;
     g.TCs = g.TC | 1;
-    while ((int64_t)H * g.TCs > G_BUF_ELEMS && g.TC > 1) { // keep H * TCs within the buffer
+    while ((int64_t)H * g.TCs > g.cbuf && g.TC > 1) { // keep H * TCs within the buffer
         g.TC -= 1;
         g.TCs = g.TC | 1;
     }
@@ -58,7 +71,7 @@ template <int IN_MODE>
 __global__ void __launch_bounds__(G_THREADS) g_row_fwd(LatArgs a, GenGeo g, cplx* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cplx* cur = reinterpret_cast<cplx*>(smem);
-    cplx* oth = cur + G_BUF_ELEMS;
+    cplx* oth = cur + g.rbuf;
     const int64_t b = blockIdx.y;
     const int H = a.H, W = a.W;
     const int r0 = blockIdx.x * g.LP;
@@ -102,7 +115,7 @@ __global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, cplx* __
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* red = reinterpret_cast<double*>(smem); // 512 bytes
     cplx* cur = reinterpret_cast<cplx*>(smem + 512);
-    cplx* oth = cur + G_BUF_ELEMS + 16;
+    cplx* oth = cur + g.cbuf + 16;
     const int64_t b = blockIdx.y;
     const int H = a.H;
     const ZLayout L = make_layout(a);
@@ -169,7 +182,7 @@ __global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, doub
                                                        const cplx* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cplx* cur = reinterpret_cast<cplx*>(smem);
-    cplx* oth = cur + G_BUF_ELEMS;
+    cplx* oth = cur + g.rbuf;
     const int64_t b = blockIdx.y;
     const int H = a.H, W = a.W;
     const int r0 = blockIdx.x * g.LP;
@@ -212,21 +225,23 @@ __global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, doub
 
 template <int OP>
 hipError_t launch_col(const LatArgs& a, const GenGeo& g, cplx* ws, double* partials, int nblk, hipStream_t st) {
-    const size_t lds = 512 + 2 * (size_t)(G_BUF_ELEMS + 16) * sizeof(cplx);
+    const size_t lds = 512 + 2 * (size_t)(g.cbuf + 16) * sizeof(cplx);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g_col<OP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(512 + 2 * (size_t)(G_BUF_ELEMS + 16) * sizeof(cplx)));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(g_col<OP>, dim3(nblk, (unsigned)a.batch), dim3(G_THREADS), lds, st, a, g, ws, partials);
+    hipLaunchKernelGGL(g_col<OP>, dim3(nblk, (unsigned)a.batch), dim3(g.cthreads), lds, st, a, g, ws, partials);
     return hipGetLastError();
 }
 
 template <int IN_MODE> hipError_t launch_row_fwd(const LatArgs& a, const GenGeo& g, cplx* ws, hipStream_t st) {
-    const size_t lds = 2 * (size_t)G_BUF_ELEMS * sizeof(cplx);
+    const size_t lds = 2 * (size_t)g.rbuf * sizeof(cplx);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g_row_fwd<IN_MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(2 * (size_t)G_BUF_ELEMS * sizeof(cplx)));
     if (e != hipSuccess) return e;
     const int nb = (g.Hp + g.LP - 1) / g.LP;
-    hipLaunchKernelGGL(g_row_fwd<IN_MODE>, dim3(nb, (unsigned)a.batch), dim3(G_THREADS), lds, st, a, g, ws);
+    hipLaunchKernelGGL(g_row_fwd<IN_MODE>, dim3(nb, (unsigned)a.batch), dim3(g.rthreads), lds, st, a, g, ws);
     return hipGetLastError();
 }
 
@@ -281,12 +296,12 @@ hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partia
         if (op == OP_INV_RFFT2) alpha = 1.0 / n;
         else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
         else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
-        const size_t lds = 2 * (size_t)G_BUF_ELEMS * sizeof(cplx);
+        const size_t lds = 2 * (size_t)g.rbuf * sizeof(cplx);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g_row_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
+                                (int)(2 * (size_t)G_BUF_ELEMS * sizeof(cplx)));
         if (e != hipSuccess) return e;
         const int nb = (g.Hp + g.LP - 1) / g.LP;
-        hipLaunchKernelGGL(g_row_inv, dim3(nb, (unsigned)a.batch), dim3(G_THREADS), lds, st, a, g, alpha, add_loc, ws);
+        hipLaunchKernelGGL(g_row_inv, dim3(nb, (unsigned)a.batch), dim3(g.rthreads), lds, st, a, g, alpha, add_loc, ws);
         e = hipGetLastError();
     }
     return e;

@@ -2,6 +2,7 @@
 // the small-lattice kernel and the generic three-pass kernels.
 #pragma once
 #include "gpt_common.h"
+#include "gpt_bfly.h"
 
 // One Stockham stage of radix R (compile-time) over `nlines` lines living in LDS: one work item = one BUTTERFLY
 // (R inputs M = N/R apart, R outputs Ns apart), inputs and twiddles loaded once per butterfly, the R-point DFT
@@ -35,16 +36,20 @@ __device__ __forceinline__ void stage_lds(const cplx* src, cplx* dst, const cplx
         }
         cplx* out = dst + (int64_t)line * ls + (int64_t)(hi * Ns * R + k) * es;
         const int64_t os = (int64_t)Ns * es;
-        if (R == 2) {
+        if constexpr (R == 2) {
             out[0] = cadd(x[0], x[1]);
             out[os] = csub(x[0], x[1]);
-        } else if (R == 4) {
+        } else if constexpr (R == 4) {
             const cplx a = cadd(x[0], x[2]), b = csub(x[0], x[2]), c = cadd(x[1], x[3]), d0 = csub(x[1], x[3]);
             const cplx d = INVERSE ? make_double2(-d0.y, d0.x) : make_double2(d0.y, -d0.x); // -+ i (x1 - x3)
             out[0] = cadd(a, c);
             out[os] = cadd(b, d);
             out[2 * os] = csub(a, c);
             out[3 * os] = csub(b, d);
+        } else if constexpr (R == 8 || R == 16) { // register butterflies of the power-of-two kernels: one LDS pass for 3 / 4 bits
+            pow2::Bfly<R, INVERSE>::run(x);
+#pragma unroll
+            for (int p = 0; p < R; ++p) out[p * os] = x[p];
         } else {
 #pragma unroll
             for (int p = 0; p < R; ++p) {
@@ -62,7 +67,7 @@ __device__ __forceinline__ void stage_lds(const cplx* src, cplx* dst, const cplx
 }
 
 // Stockham autosort stage loop over `nlines` lines living in LDS. Element e of line l sits at
-// src[l * ls + e * es]. Radices 2, 3, 4, 5, 7, 11, 13 take stage_lds; any other prime (e.g. 67: n = 134 = 2 * 67)
+// src[l * ls + e * es]. Radices 2, 3, 4, 5, 7, 8, 11, 13, 16 take stage_lds (8 and 16: only plans that ask for them); any other prime (e.g. 67: n = 134 = 2 * 67)
 // the generic loop below: one work item = one OUTPUT element (R complex MACs against the w_N table).
 // Returns the buffer that holds the result.
 template <bool INVERSE>
@@ -78,6 +83,8 @@ __device__ cplx* fft_lines_lds(cplx* src, cplx* dst, const LinePlan& p, int nlin
         case 4: stage_lds<4, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
         case 5: stage_lds<5, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
         case 7: stage_lds<7, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
+        case 8: stage_lds<8, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
+        case 16: stage_lds<16, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
         case 11: stage_lds<11, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
         case 13: stage_lds<13, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
         default: done = false;
