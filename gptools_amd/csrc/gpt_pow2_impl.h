@@ -31,6 +31,9 @@
 #ifndef GPT_TRACE
 #define GPT_TRACE 0
 #endif
+#ifndef GPT_ROWS_SAME
+#define GPT_ROWS_SAME 0
+#endif
 #if GPT_TRACE
 // debug builds only (scripts/trace_col.py): phase timestamps (100 MHz clock) of wave 0 of every column workgroup
 __device__ unsigned long long g_col_trace[1024 * 8 * 8];
@@ -300,7 +303,11 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
     const int npairs = H / 2;
     const int r = (int)(lin / gridDim.y) * LINES + line; // row pair
     const bool active = r < npairs;
+#if GPT_ROWS_SAME // timing-only builds (scripts/mkvar.sh): every workgroup works on row pair 0 -- the pass without its HBM traffic
+    const int rr = 0;
+#else
     const int rr = active ? r : 0;
+#endif
     const double* src = in_mode == 2 ? a.aux + b * a.aux_bs : a.x + b * a.x_bs;
     const int ra = SUB2 ? rr : 2 * rr, rb = SUB2 ? rr + H / 2 : 2 * rr + 1; // the two rows of this line
     const double* r0 = src + (int64_t)ra * W;
@@ -397,7 +404,11 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
     const int H = a.H;
     const int r = blockIdx.x * LINES + line;
     const bool active = r < H / 2;
+#if GPT_ROWS_SAME
+    const int rr = 0;
+#else
     const int rr = active ? r : 0;
+#endif
     const int ra = SUB2 ? rr : 2 * rr, rb = SUB2 ? rr + H / 2 : 2 * rr + 1;
     const cplx* s0 = ws + ((int64_t)b * H + ra) * wstride;
     const cplx* s1 = ws + ((int64_t)b * H + rb) * wstride;
