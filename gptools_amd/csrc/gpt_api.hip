@@ -190,10 +190,10 @@ struct gpt_ctx {
     HostPipe* pipe = nullptr; // pinned staging ring of the host-pointer entry points (created on first large transfer)
     unsigned char* scratch = nullptr; // this device's copy of the built-in scratch array (gpt_gp_rfft2_lpdf_vjp_noalloc)
     gpt_anyn* anyn = nullptr; // plans, tables and scratch of the any-length path (gpt_anyn.hip), created on first use
-    // Pinned bounce area of the host-pointer entry points for transfers too small for the ring: arrays are packed into it
-    // so that every copy of a call is asynchronous and the call synchronises once (a pageable hipMemcpyAsync stalls the
-    // host per copy: 225 -> ~70 us per call at 64 x 64).
-    char* bounce = nullptr;
+    // Pinned, device-mapped bounce area of the host-pointer entry points for transfers too small for the ring (Stager):
+    // small calls let the kernels read and write it directly, mid-size ones stage their asynchronous copies in it.
+    char* bounce = nullptr;     // host view
+    char* bounce_dev = nullptr; // device view of the same memory
     size_t bounce_bytes = 0;
 };
 
@@ -1328,35 +1328,58 @@ struct Stager {
         if (!drained) (void)hipStreamSynchronize(c->stream);
     }
     // Small calls (the docs models: 35 x 60, n = 100 ... 200; everything up to TINY_BYTES of arena): what costs there is
-    // the number of copy <-> kernel hand-overs on the stream (~12 us each), not bytes. The bounce area mirrors the arena
-    // offset for offset, the inputs go up in ONE copy (go()), the outputs and scalars come down in ONE copy (finish()).
-    static constexpr size_t TINY_BYTES = (size_t)16 << 20; // = BOUNCE_BYTES: lattices up to 256 x 256
-    bool tiny = false, flushed = false;
-    size_t up_end = 0; // end of the uploaded part of the arena
-    struct Xpose {
-        void *t, *d;
-        int R, C, esz;
-    };
-    std::vector<Xpose> xposes; // transposes of column-major inputs, launched behind the one upload
+    // the number of operations on the stream and above all the copy <-> kernel hand-overs (~12 us each), not bytes. So
+    // these calls make NO copies: the caller's arrays are memcpy'd into the context's pinned, device-mapped bounce area
+    // and the kernels read them there (the transposes of column-major matrices, or the transform kernels themselves);
+    // outputs and scalars are written by the kernels straight into the bounce area and memcpy'd out after the one
+    // synchronisation of the call. Only kernels on the stream: 64 x 64 column-major 225 -> 94 (one copy each way) -> ~50 us.
+    static constexpr size_t TINY_BYTES = (size_t)64 << 20; // = BOUNCE_BYTES: lattices up to 512 x 512
+    bool tiny = false;
     Stager(gpt_ctx* ctx, int lay, size_t need) : c(ctx), layout(lay) {
         if (hipSetDevice(c->device) != hipSuccess) {
             rc = fail(c, GPT_ERR_HIP, "hipSetDevice failed");
             return;
         }
         rc = ensure(c, c->arena, c->arena_bytes, need);
-        tiny = rc == GPT_OK && need <= TINY_BYTES && bounce_ready() && need <= c->bounce_bytes;
+        tiny = rc == GPT_OK && need <= TINY_BYTES && bounce_ready() && c->bounce_dev && need <= c->bounce_bytes;
     }
-    char* mirror(const void* dev_ptr) { return c->bounce + (static_cast<const char*>(dev_ptr) - c->arena); }
+    // the two views of the bounce area
+    void* to_dev(char* host_ptr) { return c->bounce_dev + (host_ptr - c->bounce); }
+    char* to_host(const void* dev_ptr) { return c->bounce + (static_cast<const char*>(dev_ptr) - c->bounce_dev); }
+    bool is_matrix(int64_t R, int64_t C) const { return layout == GPT_COL_MAJOR && R > 1 && C > 1; }
+    // transposes of a small call, gathered: inputs are launched together by go(), outputs by finish()
+    XposeBatch xq{};
+    int xq_esz = 0;
+    void xflush() {
+        if (xq.n == 0) return;
+        const hipError_t e = gpt_launch_transpose_multi(xq, xq_esz, c->stream);
+        if (e != hipSuccess && rc == GPT_OK) rc = hip_fail(c, e, "transpose");
+        xq.n = 0;
+    }
+    void xpose(const void* in, void* out, int R, int C, int esz) {
+        if (xq.n == GPT_XPOSE_MAX || (xq.n && xq_esz != esz)) xflush();
+        xq_esz = esz;
+        xq.in[xq.n] = in;
+        xq.out[xq.n] = out;
+        xq.R[xq.n] = R;
+        xq.C[xq.n] = C;
+        xq.n++;
+    }
     // after the uploads and before the first kernel of the call: returns rc
     int go() {
-        if (rc != GPT_OK || !tiny || flushed) return rc;
-        flushed = true;
-        hipError_t e = hipSuccess;
-        if (up_end) e = hipMemcpyAsync(c->arena, c->bounce, up_end, hipMemcpyHostToDevice, c->stream);
-        for (const Xpose& x : xposes)
-            if (e == hipSuccess) e = gpt_launch_transpose(x.t, x.d, x.R, x.C, 1, x.esz, c->stream);
-        if (e != hipSuccess) rc = hip_fail(c, e, "upload");
+        xflush();
         return rc;
+    }
+    // a scalar input next to device-side results (d from dev())
+    void put(double* d, double v) {
+        if (rc != GPT_OK) return;
+        if (tiny) {
+            *reinterpret_cast<double*>(to_host(d)) = v; // (the stream is idle between calls: nothing reads this yet)
+            return;
+        }
+        c->pinned[1] = v; // (slot 0 is the min_eig read-back of finish())
+        const hipError_t e = hipMemcpyAsync(d, c->pinned + 1, sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) rc = hip_fail(c, e, "scalar upload");
     }
     // large transfers go through the context's pinned ring (HostPipe), small ones through the runtime's pageable path
     bool piped(size_t bytes) {
@@ -1369,7 +1392,7 @@ struct Stager {
         return true;
     }
     // small transfers: a piece of the context's pinned bounce area (null: none to be had, the pageable path still works)
-    static constexpr size_t BOUNCE_BYTES = 8 * HostPipe::MIN_BYTES;
+    static constexpr size_t BOUNCE_BYTES = 32 * HostPipe::MIN_BYTES; // 64 MiB
     size_t boff = 0;
     struct Pending {
         void* host;
@@ -1380,15 +1403,21 @@ struct Stager {
     bool bounce_ready() {
         if (c->bounce) return true;
         void* p = nullptr;
-        if (hipHostMalloc(&p, BOUNCE_BYTES, hipHostMallocDefault) != hipSuccess) return false;
+        if (hipHostMalloc(&p, BOUNCE_BYTES, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return false;
         c->bounce = static_cast<char*>(p);
         c->bounce_bytes = BOUNCE_BYTES;
+        void* d = nullptr;
+        c->bounce_dev = hipHostGetDevicePointer(&d, p, 0) == hipSuccess ? static_cast<char*>(d) : nullptr;
         return true;
     }
     char* bounce(size_t bytes) {
         if (!bounce_ready()) return nullptr;
         const size_t need = (bytes + 255) & ~(size_t)255;
-        if (boff + need > c->bounce_bytes) return nullptr;
+        if (boff + need > c->bounce_bytes) {
+            // (cannot happen for a small call: its arrays fit arena_need() <= the bounce area; the caller falls back or fails)
+            if (tiny && rc == GPT_OK) rc = fail(c, GPT_ERR_ALLOC, "pinned bounce area exhausted");
+            return tiny ? c->bounce : nullptr; // a valid address, never used once rc is set
+        }
         char* p = c->bounce + boff;
         boff += need;
         return p;
@@ -1418,18 +1447,15 @@ struct Stager {
     const void* up(const void* host, int64_t R, int64_t C, int esz) {
         if (rc != GPT_OK || !host) return nullptr;
         const size_t bytes = (size_t)R * C * esz;
-        void* d = bump(bytes);
         if (tiny) {
-            if (layout == GPT_COL_MAJOR && R > 1 && C > 1) {
-                void* t = bump(bytes);
-                memcpy(mirror(t), host, bytes);
-                xposes.push_back({t, d, (int)C, (int)R, esz});
-            } else {
-                memcpy(mirror(d), host, bytes);
-            }
-            up_end = off;
+            char* b = bounce(bytes);
+            memcpy(b, host, bytes);
+            if (!is_matrix(R, C)) return to_dev(b); // the kernels read it where it is
+            void* d = bump(bytes);
+            xpose(to_dev(b), d, (int)C, (int)R, esz);
             return d;
         }
+        void* d = bump(bytes);
         hipError_t e;
         if (layout == GPT_COL_MAJOR && R > 1 && C > 1) {
             void* t = bump(bytes);
@@ -1441,21 +1467,25 @@ struct Stager {
         if (e != hipSuccess) rc = hip_fail(c, e, "upload");
         return d;
     }
-    void* dev(int64_t R, int64_t C, int esz) { return bump((size_t)R * C * esz); }
+    // room for an R x C result of the kernels (small calls: what needs no transpose lives in the bounce area already)
+    void* dev(int64_t R, int64_t C, int esz) {
+        const size_t bytes = (size_t)R * C * esz;
+        if (tiny && !is_matrix(R, C)) return to_dev(bounce(bytes));
+        return bump(bytes);
+    }
     // download a row-major device R x C matrix into the caller's layout
     void down(void* host, void* d, int64_t R, int64_t C, int esz) {
         if (rc != GPT_OK || !host) return;
         const size_t bytes = (size_t)R * C * esz;
         hipError_t e;
-        if (tiny) { // the whole output part of the arena comes down in one copy (finish)
-            const void* src = d;
-            if (layout == GPT_COL_MAJOR && R > 1 && C > 1) {
-                void* t = bump(bytes);
-                e = gpt_launch_transpose(d, t, (int)R, (int)C, 1, esz, c->stream);
-                if (e != hipSuccess) rc = hip_fail(c, e, "download");
-                src = t;
+        if (tiny) {
+            if (is_matrix(R, C)) {
+                char* b = bounce(bytes);
+                xpose(d, to_dev(b), (int)R, (int)C, esz);
+                pending.push_back({host, b, bytes});
+            } else {
+                pending.push_back({host, to_host(d), bytes}); // (d came from dev(): a piece of the bounce area)
             }
-            pending.push_back({host, mirror(src), bytes});
             return;
         }
         if (layout == GPT_COL_MAJOR && R > 1 && C > 1) {
@@ -1468,15 +1498,10 @@ struct Stager {
         if (e != hipSuccess) rc = hip_fail(c, e, "download");
     }
     int finish(double* d_min_eig) {
+        xflush();
         if (rc != GPT_OK) return rc;
         double mn = INFINITY;
-        if (tiny) {
-            if (off > up_end) {
-                hipError_t e = hipMemcpyAsync(c->bounce + up_end, c->arena + up_end, off - up_end, hipMemcpyDeviceToHost,
-                                              c->stream);
-                if (e != hipSuccess) return hip_fail(c, e, "download");
-            }
-        } else if (d_min_eig) {
+        if (!tiny && d_min_eig) {
             hipError_t e = hipMemcpyAsync(c->pinned, d_min_eig, sizeof(double), hipMemcpyDeviceToHost, c->stream);
             if (e != hipSuccess) return hip_fail(c, e, "min_eig read-back");
         }
@@ -1486,7 +1511,7 @@ struct Stager {
         for (const Pending& p : pending) memcpy(p.host, p.src, p.bytes);
         pending.clear();
         if (d_min_eig) {
-            mn = tiny ? *reinterpret_cast<const double*>(mirror(d_min_eig)) : c->pinned[0];
+            mn = tiny ? *reinterpret_cast<const double*>(to_host(d_min_eig)) : c->pinned[0];
             c->last_min_eig = mn;
             if (mn < 0) {
                 char buf[128];
@@ -1569,8 +1594,8 @@ int gpt_gp_inv_rfft2_obs_lpdf_host(gpt_ctx* c, int layout, int family, const dou
         HIP_TRY(c, gpt_launch_fill(dfill, H * W, loc_scalar, c->stream));
         dl = dfill;
     }
-    c->pinned[1] = theta; // (slot 0 is the min_eig read-back of finish(); the stream is idle between calls)
-    HIP_TRY(c, hipMemcpyAsync(dsc, c->pinned + 1, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    s.put(dsc, theta);
+    if (s.rc) return s.rc;
     if ((rc = gpt_gp_inv_rfft2_obs_lpdf_vjp(c, family, dz, 0, dl, 0, dc, 0, dob, 0, oh, ow,
                                             family == GPT_OBS_POISSON_LOG ? nullptr : dsc, prior, H, W, 1, dim1, dsc + 1,
                                             nullptr, dgz, nullptr, dsc + 2, dgc, dsc + 3, dsc + 4)))

@@ -286,7 +286,45 @@ __global__ void __launch_bounds__(256) transpose_kernel(const T* in, T* out, int
     }
 }
 
+// up to GPT_XPOSE_MAX transposes of different shapes in one launch (the small calls of the host-pointer entry points:
+// a launch costs more than the transposes themselves)
+template <typename T> __global__ void __launch_bounds__(256) transpose_multi_kernel(XposeBatch b) {
+    __shared__ T tile[32][33];
+    int k = 0;
+    while (k + 1 < b.n && (int)blockIdx.x >= b.first_tile[k + 1]) ++k;
+    const int t = blockIdx.x - b.first_tile[k];
+    const int R = b.R[k], C = b.C[k], nbx = (C + 31) / 32;
+    const T* ib = static_cast<const T*>(b.in[k]);
+    T* ob = static_cast<T*>(b.out[k]);
+    const int by = t / nbx, bx = t - by * nbx;
+    const int c0 = bx * 32, r0 = by * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int q = ty; q < 32; q += 8) {
+        const int r = r0 + q, c = c0 + tx;
+        if (r < R && c < C) tile[q][tx] = ib[(int64_t)r * C + c];
+    }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {
+        const int c = c0 + q, r = r0 + tx;
+        if (r < R && c < C) ob[(int64_t)c * R + r] = tile[tx][q];
+    }
+}
+
 } // namespace
+
+hipError_t gpt_launch_transpose_multi(XposeBatch b, int esz, hipStream_t st) {
+    if (b.n <= 0) return hipSuccess;
+    if (b.n > GPT_XPOSE_MAX) return hipErrorInvalidValue;
+    int tiles = 0;
+    for (int k = 0; k < b.n; ++k) {
+        b.first_tile[k] = tiles;
+        tiles += ((b.C[k] + 31) / 32) * ((b.R[k] + 31) / 32);
+    }
+    if (esz == 8) hipLaunchKernelGGL(transpose_multi_kernel<double>, dim3((unsigned)tiles), dim3(256), 0, st, b);
+    else if (esz == 16) hipLaunchKernelGGL(transpose_multi_kernel<cplx>, dim3((unsigned)tiles), dim3(256), 0, st, b);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
 
 int gpt_elem_blocks(int H, int W) {
     const int64_t tot = (int64_t)H * (W / 2 + 1);

@@ -108,6 +108,16 @@ hipError_t gpt_launch_kvjp_combine(const double* ksums, const double* params, in
                                    double* params_bar, hipStream_t st);
 // Row-major <-> column-major (Stan/Eigen) transposes of a batch of R x C matrices of `esz`-byte elements.
 hipError_t gpt_launch_transpose(const void* in, void* out, int R, int C, int64_t batch, int esz, hipStream_t st);
+// several R[k] x C[k] matrices of esz-byte elements in one launch
+#define GPT_XPOSE_MAX 4
+struct XposeBatch {
+    const void* in[GPT_XPOSE_MAX];
+    void* out[GPT_XPOSE_MAX];
+    int R[GPT_XPOSE_MAX], C[GPT_XPOSE_MAX];
+    int first_tile[GPT_XPOSE_MAX]; // filled by the launcher
+    int n;
+};
+hipError_t gpt_launch_transpose_multi(XposeBatch b, int esz, hipStream_t st);
 
 // --- observation models on the latent field (gpt_obs.hip); families as in include/gptools_hip.h
 struct ObsArgs {
