@@ -274,6 +274,48 @@ def test_host_entry_points_col_major(fft):
         assert lib.gpt_last_min_eig(ctx.handle) < 0
 
 
+@pytest.mark.parametrize("shape", [(35, 60), (110, 110), (256, 256), (512, 256), (1, 176), (1, 8192), (6, 5000)],
+                         ids=lambda s: f"{s[0]}x{s[1]}")
+def test_host_entry_points_row_major_small_calls(fft, shape):
+    """Row-major host arrays through the copy-free small-call route of the host ABI: the transform kernels of every path
+    (one workgroup per lattice, generic, power-of-two three-pass, any-length) read their inputs from, and write their
+    results to, the pinned device-mapped bounce area directly. Twice in a row (the area is reused)."""
+    import ctypes
+
+    from gptools_amd import _lib
+
+    lib = _lib.load()
+    ctx = fft.get_context()
+    h, w = shape
+    dim1 = int(h == 1)
+    wf = w // 2 + 1
+    rng = np.random.default_rng(13 * h + w)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    for rep in range(2):
+        y, loc, z = rng.normal(size=(h, w)), rng.normal(size=(h, w)), rng.normal(size=(h, w))
+        cov = np.exp(0.3 * rng.normal(size=(h, wf)))
+        lp, gy, gc = np.zeros(1), np.zeros((h, w)), np.zeros((h, wf))
+        rc = lib.gpt_gp_rfft2_lpdf_host(ctx.handle, _lib.GPT_ROW_MAJOR, P(y), P(loc), P(cov), h, w, dim1, P(lp), P(gy), P(gc))
+        assert rc == 0, ctx.error()
+        if dim1:
+            lp_o, gy_o, gc_o = o.gp_rfft_lpdf_vjp(y[0], loc[0], cov[0])
+            gy_o, gc_o = gy_o[None], gc_o[None]
+        else:
+            lp_o, gy_o, gc_o = o.gp_rfft2_lpdf_vjp(y, loc, cov)
+        close(lp[0], lp_o)
+        close(gy, gy_o)
+        close(gc, gc_o)
+        out = np.zeros((h, w))
+        assert lib.gpt_gp_rfft2_host(ctx.handle, _lib.GPT_ROW_MAJOR, P(y), P(loc), P(cov), h, w, dim1, P(out)) == 0, ctx.error()
+        close(out, o.gp_rfft(y[0], loc[0], cov[0])[None] if dim1 else o.gp_rfft2(y, loc, cov))
+        assert lib.gpt_gp_inv_rfft2_host(ctx.handle, _lib.GPT_ROW_MAJOR, P(z), P(loc), P(cov), h, w, dim1, P(out)) == 0, ctx.error()
+        close(out, o.gp_inv_rfft(z[0], loc[0], cov[0])[None] if dim1 else o.gp_inv_rfft2(z, loc, cov))
+        # value only, no loc
+        assert lib.gpt_gp_rfft2_lpdf_host(ctx.handle, _lib.GPT_ROW_MAJOR, P(y), None, P(cov), h, w, dim1, P(lp), None, None) == 0
+        zero = np.zeros((h, w))
+        close(lp[0], (o.gp_rfft_lpdf(y[0], zero[0], cov[0]) if dim1 else o.gp_rfft2_lpdf(y, zero, cov)))
+
+
 # ---- three-pass paths (lattices too large for one workgroup's LDS) ----------------------------------
 BIG_SHAPES = [(256, 256), (256, 512), (512, 256), (1024, 256), (2048, 512), (512, 2048), (8192, 256), (256, 8192),
               (256, 16384),  # every line length of the power-of-two kernels
