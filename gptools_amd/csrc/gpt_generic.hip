@@ -10,6 +10,20 @@
 #include "gpt_host.h"
 #include "gpt_lds_fft.h"
 
+#ifndef GPT_TRACE
+#define GPT_TRACE 0
+#endif
+#if GPT_TRACE
+// debug builds only (scripts/trace_gen.py): phase timestamps (100 MHz clock) of thread 0 of column workgroup 1, lattice 0
+__device__ unsigned long long g_gen_trace[16];
+#define GMARK(k_)                                                                                   \
+    do {                                                                                            \
+        if (threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == 0) g_gen_trace[k_] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define GMARK(k_) ((void)0)
+#endif
+
 namespace {
 
 constexpr int G_THREADS = 512;
@@ -124,22 +138,30 @@ __global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, cplx* __
     const int nc = min(g.TC, g.NC - j0);
     const int sS = g.TCs;
     cplx* wsb = ws + (int64_t)b * H * g.wstride;
+    const unsigned mnc = fastdiv_magic((unsigned)nc);
+    GMARK(0);
     if (op_has_fwd(OP)) {
+        // (unrolled: the loads of eight iterations are in flight together; one workgroup per CU has nothing else to hide
+        // a memory latency per iteration behind)
+#pragma unroll 8
         for (int w = threadIdx.x; w < H * nc; w += blockDim.x) {
-            const int k = w / nc, c = w - k * nc;
-            cur[k * sS + c] = wsb[(int64_t)k * g.wstride + j0 + c];
+            const int k = (int)fastdiv((unsigned)w, (unsigned)nc, mnc), c = w - k * nc;
+            cur[k * sS + c] = wsb[(unsigned)k * (unsigned)g.wstride + (unsigned)(j0 + c)];
         }
         __syncthreads();
+        GMARK(1);
         cplx* res = fft_lines_lds<false>(cur, oth, a.ph, nc, sS, 1);
         if (res != cur) {
             oth = cur;
             cur = res;
         }
     }
+    GMARK(2);
     EwAcc acc;
     acc_init(acc);
+#pragma unroll 4
     for (int w = threadIdx.x; w < H * nc; w += blockDim.x) {
-        const int k = w / nc, c = w - k * nc;
+        const int k = (int)fastdiv((unsigned)w, (unsigned)nc, mnc), c = w - k * nc;
         const int jp = j0 + c;
         if (jp == 0) continue;
         const cplx G = ew_interior<OP>(a, L, P, k, jp, cur[k * sS + c], acc);
@@ -159,12 +181,15 @@ __global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, cplx* __
     }
     acc_fold(acc);
     __syncthreads();
+    GMARK(3);
     if (op_has_inv(OP)) {
         const cplx* res = fft_lines_lds<true>(cur, oth, a.ph, nc, sS, 1);
+        GMARK(4);
         for (int w = threadIdx.x; w < H * nc; w += blockDim.x) {
-            const int k = w / nc, c = w - k * nc;
-            wsb[(int64_t)k * g.wstride + j0 + c] = res[k * sS + c];
+            const int k = (int)fastdiv((unsigned)w, (unsigned)nc, mnc), c = w - k * nc;
+            wsb[(unsigned)k * (unsigned)g.wstride + (unsigned)(j0 + c)] = res[k * sS + c];
         }
+        GMARK(5);
     }
     if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
         double s = acc.sum, mn = acc.mn;
@@ -306,3 +331,11 @@ hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partia
     }
     return e;
 }
+
+#if GPT_TRACE
+extern "C" int gpt_debug_gen_trace(unsigned long long* dst, size_t n) {
+    if (n > 16) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gen_trace), n * sizeof(unsigned long long));
+}
+#endif

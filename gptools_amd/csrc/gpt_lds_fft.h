@@ -18,7 +18,12 @@ __device__ __forceinline__ void stage_lds(const cplx* __restrict__ src, cplx* __
                                           const cplx* __restrict__ tw, int N, int Ns, int nlines, int es, int ls) {
     const int M = N / R, tstep = N / (Ns * R), total = nlines * M;
     // (unrolling this loop 2-4 times so that the next butterfly's loads are issued early was measured: 10-20 % slower)
-    const unsigned mM = fastdiv_magic((unsigned)M), mNs = fastdiv_magic((unsigned)Ns);
+    const unsigned mM = fastdiv_magic((unsigned)M), mNs = fastdiv_magic((unsigned)Ns), mL = fastdiv_magic((unsigned)nlines);
+    // Work items are numbered so that neighbouring lanes touch neighbouring LDS addresses: along a line when its
+    // elements are contiguous (es == 1: row tiles), across the lines when the lines are interleaved (ls == 1: column
+    // tiles, element stride = tile width -- numbered along the line, every access of a wave was a 2- to 4-way bank
+    // conflict).
+    const bool across = (ls == 1 && es > 1);
     cplx wr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -27,7 +32,14 @@ __device__ __forceinline__ void stage_lds(const cplx* __restrict__ src, cplx* __
     }
 #pragma unroll 1
     for (int w = threadIdx.x; w < total; w += blockDim.x) {
-        const int line = (int)fastdiv((unsigned)w, (unsigned)M, mM), j = w - line * M;
+        int line, j;
+        if (across) {
+            j = (int)fastdiv((unsigned)w, (unsigned)nlines, mL);
+            line = w - j * nlines;
+        } else {
+            line = (int)fastdiv((unsigned)w, (unsigned)M, mM);
+            j = w - line * M;
+        }
         const int hi = (int)fastdiv((unsigned)j, (unsigned)Ns, mNs), k = j - hi * Ns;
         const cplx* in = src + (line * ls + j * es); // (LDS: 32-bit offsets)
         cplx x[R];
@@ -35,6 +47,8 @@ __device__ __forceinline__ void stage_lds(const cplx* __restrict__ src, cplx* __
         for (int q = 0; q < R; ++q) x[q] = in[q * M * es];
         if (Ns > 1) {
             const int e = k * tstep; // q e < N for q < R
+            // (computing w^e with sincospi instead of loading it, for stages with only a butterfly or two per thread, was
+            // measured: no faster per workgroup, 15-25 % slower per launch)
 #pragma unroll
             for (int q = 1; q < R; ++q) {
                 cplx t = tw[q * e];
@@ -133,10 +147,18 @@ __device__ cplx* fft_lines_lds(cplx* src, cplx* dst, const LinePlan& p, int nlin
         const int M = N / R;
         const int tstep = N / (Ns * R);
         const int total = nlines * N;
-        const unsigned mN = fastdiv_magic((unsigned)N), mNs = fastdiv_magic((unsigned)Ns), mR = fastdiv_magic((unsigned)R);
+        const unsigned mN = fastdiv_magic((unsigned)N), mNs = fastdiv_magic((unsigned)Ns), mR = fastdiv_magic((unsigned)R),
+                       mL = fastdiv_magic((unsigned)nlines);
+        const bool across = (ls == 1 && es > 1); // (as in stage_lds)
         for (int w = threadIdx.x; w < total; w += blockDim.x) {
-            const int line = (int)fastdiv((unsigned)w, (unsigned)N, mN);
-            const int o = w - line * N;
+            int line, o;
+            if (across) {
+                o = (int)fastdiv((unsigned)w, (unsigned)nlines, mL);
+                line = w - o * nlines;
+            } else {
+                line = (int)fastdiv((unsigned)w, (unsigned)N, mN);
+                o = w - line * N;
+            }
             const int t = (int)fastdiv((unsigned)o, (unsigned)Ns, mNs);
             const int k = o - t * Ns;
             const int th = (int)fastdiv((unsigned)t, (unsigned)R, mR);
