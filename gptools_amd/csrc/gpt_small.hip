@@ -35,11 +35,14 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
     const bool weven = (W % 2) == 0;
     cplx* cur = buf0;
     cplx* oth = buf1;
+    // (index arithmetic of the element loops: multiply-high instead of integer division, gpt_lds_fft.h)
+    const unsigned mW = fastdiv_magic((unsigned)W), mNC = fastdiv_magic((unsigned)NC),
+                   mwc = fastdiv_magic((unsigned)(L.wc > 0 ? L.wc : 1));
 
     if (op_has_fwd(OP)) {
         // load: line r = rows (2r, 2r+1)
         for (int w = threadIdx.x; w < Hp * W; w += blockDim.x) {
-            const int r = w / W, j = w - r * W;
+            const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
             const double re = in_transform<OP>(a, b, 2 * r, j);
             const double im = (2 * r + 1 < H) ? in_transform<OP>(a, b, 2 * r + 1, j) : 0.0;
             cur[w] = make_double2(re, im);
@@ -52,7 +55,7 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         }
         // split row pairs -> packed spectrum S[i * sS + jp] in `oth`
         for (int w = threadIdx.x; w < H * NC; w += blockDim.x) {
-            const int i = w / NC, jp = w - i * NC;
+            const int i = (int)fastdiv((unsigned)w, (unsigned)NC, mNC), jp = w - i * NC;
             const cplx* line = cur + (i >> 1) * W;
             auto rowspec = [&](int j) -> cplx {
                 const cplx z = line[j];
@@ -87,7 +90,7 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
     EwAcc acc;
     acc_init(acc);
     for (int w = threadIdx.x; w < H * L.wc; w += blockDim.x) {
-        const int i = w / L.wc, j = 1 + (w - i * L.wc);
+        const int i = (int)fastdiv((unsigned)w, (unsigned)L.wc, mwc), j = 1 + (w - i * L.wc);
         const cplx F = cur[i * sS + j];
         const cplx G = ew_interior<OP>(a, L, P, i, j, F, acc);
         if (op_has_inv(OP)) cur[i * sS + j] = G;
@@ -137,7 +140,7 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         }
         // merge row pairs into complex lines of length W in `oth`
         for (int w = threadIdx.x; w < Hp * W; w += blockDim.x) {
-            const int r = w / W, j = w - r * W;
+            const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
             auto rowspec = [&](int i, int jj) -> cplx {
                 const bool mir = jj > W / 2;
                 const int q = mir ? W - jj : jj;
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         }
         res = fft_lines_lds<true>(cur, oth, a.pw, Hp, 1, W);
         for (int w = threadIdx.x; w < Hp * W; w += blockDim.x) {
-            const int r = w / W, j = w - r * W;
+            const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
             const cplx v = res[w];
             double* o = a.out + b * (int64_t)H * W;
             o[(int64_t)(2 * r) * W + j] = out_transform<OP>(a, b, 2 * r, j, v.x);
