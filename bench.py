@@ -211,30 +211,120 @@ def self_check(fft, y, loc, cov, out, per_lattice_cov):
     return errs
 
 
-def fused_kernel_extra(fft, y, loc, steps):
-    """NOT the headline: the kernel-fused entry point (gpt_gp_rfft2_lpdf_kernel_vjp, SURVEY 8(f)-4) on the same
-    lattices; its own algorithmic bytes: read y, loc, write d/dy = 24 n (no spectrum, no d/dcov in memory)."""
-    B, h, w = y.shape
-    sigma = torch.full((B,), 1.3, dtype=torch.float64, device=y.device)
-    ls = torch.tensor([8.0, 12.0], dtype=torch.float64, device=y.device).expand(B, 2)
-    per = torch.tensor([float(h), float(w)], dtype=torch.float64, device=y.device).expand(B, 2)
+def profiled_passes(ctx, step, B, prof_steps):
+    """Average duration of passes A / B / C per lattice over `prof_steps` extra, untimed steps (the library's per-pass HIP
+    events, gpt_profile_begin / gpt_profile_end) -> ([sec per evaluation] * 4, lattices per launch)."""
+    pass_ms = (ctypes.c_double * 4)()
+    launches = ctypes.c_int64(0)
+    ctx.lib.gpt_profile_begin(ctx.handle)
+    for _ in range(prof_steps):
+        step()
+    ctx.lib.gpt_profile_end(ctx.handle, pass_ms, ctypes.byref(launches))
+    if launches.value <= 0:
+        return None, None
+    return [1e-3 * pass_ms[k] / (B * prof_steps) for k in range(4)], B * prof_steps / launches.value
 
-    def step():
-        return fft.gp_rfft2_lpdf_kernel_vjp(y, loc, "matern", 1.5, sigma, ls, per, nugget=1e-3, check=False)
 
-    step()
+def event_timed(step, steps):
+    """Device seconds per step between two HIP events on the launch stream."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):
-        lp, _, _ = step()
+        step()
     e1.record()
     torch.cuda.synchronize()
-    sec = 1e-3 * e0.elapsed_time(e1) / (steps * B)
+    return 1e-3 * e0.elapsed_time(e1) / steps
+
+
+def fused_kernel_extra(fft, ctx, y, loc, steps):
+    """NOT the headline: the kernel-fused entry point (gpt_gp_rfft2_lpdf_kernel_vjp, SURVEY 8(f)-4) on the same
+    lattices, every lattice its own kernel parameters; its own algorithmic bytes: read y, loc, write d/dy = 24 n (no
+    spectrum, no d/dcov in memory). Outputs preallocated, as in the headline loop."""
+    B, h, w = y.shape
+    sigma = torch.linspace(1.25, 1.35, B, dtype=torch.float64, device=y.device)
+    ls = torch.tensor([8.0, 12.0], dtype=torch.float64, device=y.device).expand(B, 2)
+    per = torch.tensor([float(h), float(w)], dtype=torch.float64, device=y.device).expand(B, 2)
+    out = (torch.empty(B, dtype=torch.float64, device=y.device), torch.empty_like(y),
+           torch.empty(B, 5, dtype=torch.float64, device=y.device), torch.empty(B, dtype=torch.float64, device=y.device))
+
+    def step():
+        return fft.gp_rfft2_lpdf_kernel_vjp(y, loc, "matern", 1.5, sigma, ls, per, nugget=1e-3, check=False, out=out)
+
+    for _ in range(2):
+        step()
+    sec = event_timed(step, steps) / B
+    per_eval, lpl = profiled_passes(ctx, step, B, min(steps, 3))
     b_alg = 24 * h * w
-    return {"entry_point": "gpt_gp_rfft2_lpdf_kernel_vjp (Matern-3/2 + nugget evaluated inside the column pass)",
-            "evals_per_s": 1.0 / sec, "algorithmic_bytes_per_eval": b_alg, "achieved_GBps": b_alg / sec / 1e9,
-            "frac": b_alg / sec / HBM_PEAK, "finite": bool(torch.isfinite(lp).all()),
-            "note": "allocates its outputs inside the timed loop (shim convenience path)"}
+    rec = {"entry_point": "gpt_gp_rfft2_lpdf_kernel_vjp (Matern-3/2 + nugget evaluated inside the column pass, "
+                          "d/d(sigma, length_scale, period) reduced there; per-lattice parameters)",
+           "evals_per_s": 1.0 / sec, "algorithmic_bytes_per_eval": b_alg, "achieved_GBps": b_alg / sec / 1e9,
+           "frac": b_alg / sec / HBM_PEAK, "frac_on_headline_bytes": (24 * h * w + 16 * h * (w // 2 + 1)) / sec / HBM_PEAK,
+           "finite": bool(torch.isfinite(out[0]).all() and torch.isfinite(out[2]).all())}
+    if per_eval:
+        rec["pass_us_per_eval"] = {"row_fwd": 1e6 * per_eval[0], "col": 1e6 * per_eval[1], "row_inv": 1e6 * per_eval[3]}
+    return rec
+
+
+def unshared_leg(fft, ctx, size, B, device, steps):
+    """The same step with NOTHING shared: every lattice its own loc and its own cov, so that every byte of B_alg is a
+    distinct byte that has to come from HBM (in the headline configuration loc and cov are read about once per launch of
+    16 lattices). Same B_alg, same entry point."""
+    h = w = size
+    y, loc, cov = synthetic(fft, size, B, device, seed=101, per_lattice_cov=True)
+    g = torch.Generator(device=device)
+    g.manual_seed(13)
+    dl = torch.randn(B, h, w, dtype=torch.float64, device=device, generator=g)
+    y += dl  # y_b - loc_b is the same draw as before
+    locb = loc.unsqueeze(0) + dl
+    del dl
+    out = (torch.empty(B, dtype=torch.float64, device=device), torch.empty_like(y), torch.empty_like(cov),
+           torch.empty(B, dtype=torch.float64, device=device))
+
+    def step():
+        fft.gp_rfft2_lpdf_vjp(y, locb, cov, check=False, out=out)
+
+    for _ in range(2):
+        step()
+    sec = event_timed(step, steps) / B
+    per_eval, _ = profiled_passes(ctx, step, B, min(steps, 3))
+    b_alg = 24 * h * w + 16 * h * (w // 2 + 1)
+    ok = bool(torch.isfinite(out[0]).all()) and float(out[3].min()) >= 0.0
+    if not os.environ.get("GPT_BENCH_NOCHECK"):  # last lattice of the batch against a single-lattice call
+        lp1, gy1, gc1 = fft.gp_rfft2_lpdf_vjp(y[B - 1], locb[B - 1], cov[B - 1], check=False)
+        err = max(float((out[1][B - 1] - gy1).abs().max() / gy1.abs().max()),
+                  float((out[2][B - 1] - gc1).abs().max() / gc1.abs().max()),
+                  float((out[0][B - 1] - lp1).abs() / lp1.abs()))
+        ok = ok and err < 1e-12
+    rec = {"what": f"{B} lattices per step, one loc AND one cov per lattice (nothing shared)", "evals_per_s": 1.0 / sec,
+           "achieved": b_alg / sec / 1e9, "frac": b_alg / sec / HBM_PEAK, "valid": ok}
+    if per_eval:
+        rec["pass_us_per_eval"] = {"row_fwd": 1e6 * per_eval[0], "col": 1e6 * per_eval[1], "row_inv": 1e6 * per_eval[3]}
+    return rec
+
+
+def three_pass_ceiling(args):
+    """The same harness on gptools_amd/libvar_traffic.so (make traffic): passes A / B / C with every load and store of
+    the real kernels and no arithmetic or LDS traffic between them -- what the three-pass structure could reach on this
+    box if the transforms were free. Runs as a child process (another build of the library cannot be loaded beside the
+    real one); its results are garbage by construction and never checked."""
+    lib = os.path.join(ROOT, "gptools_amd", "libvar_traffic.so")
+    if not os.path.exists(lib):
+        return {"value": None, "note": "gptools_amd/libvar_traffic.so not built (make -C gptools_amd/csrc traffic)"}
+    env = dict(os.environ, GPT_LIB=lib, GPT_BENCH_NOCHECK="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch",
+           str(args.batch), "--size", str(args.size), "--no-cpu-baseline", "--no-extra", "--no-ceiling"]
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, check=True, env=env)
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+    except (subprocess.SubprocessError, ValueError, IndexError) as exc:
+        return {"value": None, "note": f"traffic-only run failed: {exc}"}
+    rec = {"what": "traffic-only build of passes A/B/C (loads and stores of the real kernels, no butterflies, no LDS "
+                   "exchange, no elementwise arithmetic), same harness, same workload",
+           "evals_per_s": r["value"], "frac": r["roofline"]["frac"], "achieved": r["roofline"]["achieved"]}
+    if "kernels" in r["roofline"]:
+        k = {x["name"].split()[0]: 1e3 * x["avg_ms_per_eval"] for x in r["roofline"]["kernels"]}
+        rec["pass_us_per_eval"] = {"row_fwd": k.get("row_fwd"), "col": k.get("col"), "row_inv": k.get("row_inv")}
+    return rec
 
 
 def main():
@@ -250,6 +340,8 @@ def main():
                          "all-to-all over RCCL), strong scaling")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-pass HIP-event timing")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra (non-headline) kernel-fused measurement")
+    ap.add_argument("--no-ceiling", action="store_true",
+                    help="skip roofline.unshared and roofline.three_pass_ceiling (A/B runs of tuning variants)")
     ap.add_argument("--per-lattice-cov", action="store_true",
                     help="not the headline: one spectrum per lattice (per-lattice sigma, length_scale) instead of a "
                          "spectrum shared by the batch")
@@ -329,13 +421,9 @@ def main():
     # Per-pass breakdown: extra, untimed steps with the library's per-pass HIP events.
     profile = not args.no_profile
     prof_steps = min(args.steps, 5)
-    pass_ms = (ctypes.c_double * 4)()
-    launches = ctypes.c_int64(0)
+    per_eval = lpl = None
     if profile:
-        ctx.lib.gpt_profile_begin(ctx.handle)
-        for _ in range(prof_steps):
-            step()
-        ctx.lib.gpt_profile_end(ctx.handle, pass_ms, ctypes.byref(launches))
+        per_eval, lpl = profiled_passes(ctx, step, B, prof_steps)
     barrier()
     elapsed = sharding.max_over_ranks(elapsed, device=device)  # the job's clock is its slowest rank
 
@@ -394,9 +482,7 @@ def main():
             "timing": "two HIP events around the timed region on the launch stream",
             "wall_frac": value / world * b_alg / HBM_PEAK,
         }
-        if profile and launches.value > 0:
-            per_eval = [1e-3 * pass_ms[k] / (B * prof_steps) for k in range(4)]  # seconds per evaluation
-            lpl = B * prof_steps / launches.value  # lattices per launch: the shared loc is read once per launch
+        if per_eval:  # seconds per evaluation; lpl = lattices per launch: the shared loc is read once per launch
             pass_bytes = {
                 "row_fwd (pass A)": 16 * n + int(8 * n / lpl),  # read y, loc (shared); write packed spectrum
                 "col (pass B)": 8 * n + 8 * hwf + 8 * hwf + 8 * n,  # spectrum r/w in place, read c, write dcov
@@ -430,7 +516,16 @@ def main():
             result["roofline"]["measured_copy_GBps"] = 10 * 2 * src.numel() * 8 / (1e-3 * c0.elapsed_time(c1)) / 1e9
             del src, dst
         if world == 1 and not args.no_extra:
-            result["extra"] = {"kernel_fused_lpdf": fused_kernel_extra(fft, y, loc, max(2, min(args.steps, 5)))}
+            result["extra"] = {"kernel_fused_lpdf": fused_kernel_extra(fft, ctx, y, loc, max(2, min(args.steps, 5)))}
+            # what the roofline fraction means: the same B_alg with nothing shared, and the
+            # traffic-only ceiling of the three-pass structure on this box
+        if world == 1 and not args.no_extra and not args.no_ceiling:
+            del y, gy, gc, out
+            torch.cuda.empty_cache()
+            if not args.per_lattice_cov:
+                result["roofline"]["unshared"] = unshared_leg(fft, ctx, size, B, device, max(2, min(args.steps, 5)))
+            torch.cuda.empty_cache()
+            result["roofline"]["three_pass_ceiling"] = three_pass_ceiling(args)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(size)
         print(json.dumps(result))

@@ -338,6 +338,7 @@ int run_units(gpt_ctx* c, int op, const LatArgs& a, int path, int64_t chunk, cpl
         if (s.min_eig) s.min_eig += b0;
         if (s.kpar) s.kpar += b0 * 5;
         if (s.ksums) s.ksums += b0 * 4;
+        if (s.kbar) s.kbar += b0 * 5;
         if (path == 3) {
             HIP_TRY(c, gpt_launch_anyn(c->anyn, op, s, c->stream));
             continue;
@@ -1127,7 +1128,9 @@ int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx* c, int matern, double nu, const double
     const bool fused = !dim1 && nu_ok &&
                        (path == 0 || (path == 1 && gpt_pow2_sub_radix(OP_LPDF_KVJP, (int)H, (int)W) != 0));
     if (fused) {
-        if ((rc = ensure(c, c->kscr, c->kscr_bytes, sizeof(double) * 4 * (size_t)batch)) != GPT_OK) return rc;
+        // the one-workgroup path leaves four sums per lattice for a combine launch; the three-pass path finishes
+        // inside its last pass (finalize_block) and needs no scratch
+        if (path == 0 && (rc = ensure(c, c->kscr, c->kscr_bytes, sizeof(double) * 4 * (size_t)batch)) != GPT_OK) return rc;
         LatArgs a = base_args(H, W, batch, 0);
         a.x = y; a.x_bs = y_bs;
         a.loc = loc; a.loc_bs = loc_bs;
@@ -1138,9 +1141,14 @@ int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx* c, int matern, double nu, const double
         a.knu = nu;
         a.kgamma = matern ? gamma_ratio(nu, 0) : 0.0;
         a.knugget = nugget;
-        a.ksums = c->kscr;
+        if (path == 0) {
+            a.ksums = c->kscr;
+        } else {
+            a.out_lpdf = lpdf;
+            a.kbar = params_bar;
+        }
         if ((rc = run_lattice(c, matern ? OP_LPDF_KVJP : OP_LPDF_KVJP_EQ, a)) != GPT_OK) return rc;
-        HIP_TRY(c, gpt_launch_kvjp_combine(c->kscr, params, batch, lpdf, params_bar, c->stream));
+        if (path == 0) HIP_TRY(c, gpt_launch_kvjp_combine(c->kscr, params, batch, lpdf, params_bar, c->stream));
         return GPT_OK;
     }
     // composed: cov and d/dcov live in scratch, a chunk of lattices at a time (<= ~256 MiB)

@@ -87,7 +87,9 @@ struct LatArgs {
     int kmatern;
     double knu, kgamma, knugget;
     double* ksums; // [batch][4]: log density, then the three sums of acc_kern (gpt_launch_kvjp_combine turns them
-                   // into d/d(sigma, length_scale, period))
+                   // into d/d(sigma, length_scale, period)): the one-workgroup path
+    double* kbar;  // [batch][5] d/d(sigma, length_scale, period), or null: the three-pass path writes it (and out_lpdf)
+                   // from the finalize step folded into pass C -- no separate reduction or combine launch
     // Twiddle table w_{H/4}^m of the sub-line column kernels (gpt_pow2_sub.h); null: whole-column kernels only.
     const cplx* tw_sub;
     // Slab decomposition, layouts that need no copy on either side of the exchange (0 = not used):
@@ -222,6 +224,10 @@ struct FinArgs {
     double add;
     double* out_sum; // may be null
     double* out_min; // may be null
+    // kernel-fused log density (OP_LPDF_KVJP): slots 1..3 of the partials hold the three sums of acc_kern; kpar =
+    // [batch][5] kernel parameters, kbar = [batch][5] their gradient (null: not asked for)
+    const double* kpar;
+    double* kbar;
 };
 __device__ __forceinline__ void finalize_block(const FinArgs& f, int64_t b, double* red) {
     const double* p = f.partials + b * (int64_t)f.nblk * GPT_PART;
@@ -234,6 +240,26 @@ __device__ __forceinline__ void finalize_block(const FinArgs& f, int64_t b, doub
     if (threadIdx.x == 0) {
         if (f.out_sum) f.out_sum[b] = s + f.add;
         if (f.out_min) f.out_min[b] = mn;
+    }
+    if (f.kpar && f.kbar) { // (workgroup-uniform)
+        double k[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double t = 0.0, dummy = INFINITY;
+            for (int i = threadIdx.x; i < f.nblk; i += blockDim.x) t += p[(int64_t)i * GPT_PART + 1 + q];
+            __syncthreads(); // thread 0 is done reading the previous round's red[]
+            block_sum_min(t, dummy, red);
+            k[q] = t;
+        }
+        if (threadIdx.x == 0) {
+            const double* par = f.kpar + 5 * b;
+            double* o = f.kbar + 5 * b;
+            o[0] = 2.0 * k[0] / par[0];    // sigma
+            o[1] = (k[0] - k[1]) / par[1]; // length_scale[0]
+            o[2] = (k[0] - k[2]) / par[2]; // length_scale[1]
+            o[3] = (k[1] - k[0]) / par[3]; // period[0]
+            o[4] = (k[2] - k[0]) / par[4]; // period[1]
+        }
     }
 }
 
@@ -317,6 +343,22 @@ __device__ __forceinline__ void acc_fold(EwAcc& acc) {
     acc.ex = 0;
 }
 
+// Per-lattice constants of the kernel-fused ops (kern_prepare): everything of the spectral density that does not
+// depend on the entry, computed ONCE per workgroup and made wave-uniform (scalar registers), so that an entry costs no
+// parameter load and no division by a period (they used to be redone per entry: the pins that keep the register tiles
+// from spilling also kept the compiler from hoisting them).
+struct KernPre {
+    double r1, r2; // length_scale / period per axis
+    double camp;   // ck = camp * arg^-(nu + 1)  (Matern)   or   camp * exp(-2 pi^2 (s1 + s2))  (squared exponential)
+    double tn;     // Matern: arg = 1 + tn (s1 + s2)
+    double gco;    // f = gco * s / arg (Matern), gco * s (squared exponential)
+    int m;         // Matern: nu + 1/2
+};
+__device__ __forceinline__ double gpt_uniform(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // Per-lattice base pointers (workgroup-uniform: they live in SGPRs); elements are then addressed with
 // 32-bit offsets (H * W < 2^31 as in the reference, fft2.stan:15), one VGPR per address.
 struct EwPtrs {
@@ -333,6 +375,7 @@ struct EwPtrs {
     const double* edge_cov;
     double* edge_dcov;
     const double* kpar; // OP_LPDF_KVJP: this lattice's kernel parameters
+    KernPre kp;         // ... and what kern_prepare made of them
 };
 
 __device__ __forceinline__ EwPtrs make_ptrs(const LatArgs& a, int64_t b) {
@@ -348,7 +391,31 @@ __device__ __forceinline__ EwPtrs make_ptrs(const LatArgs& a, int64_t b) {
     P.edge_cov = nullptr;
     P.edge_dcov = nullptr;
     P.kpar = a.kpar ? a.kpar + b * 5 : nullptr;
+    P.kp.r1 = P.kp.r2 = P.kp.camp = P.kp.tn = P.kp.gco = 0.0;
+    P.kp.m = 0;
     return P;
+}
+// Kernels that run the kernel-fused ops call this once after make_ptrs (workgroup-uniform control flow).
+template <int OP> __device__ __forceinline__ void kern_prepare(const LatArgs& a, EwPtrs& P) {
+    if (!op_is_kvjp(OP)) return;
+    constexpr double PI_ = 3.14159265358979323846;
+    const double* par = P.kpar;
+    const double sigma = par[0], l1 = par[1], l2 = par[2], p1 = par[3], p2 = par[4];
+    const double r1 = l1 / p1, r2 = l2 / p2;
+    const double amp = sigma * sigma * (double)a.H * (double)a.W * r1 * r2;
+    P.kp.r1 = gpt_uniform(r1);
+    P.kp.r2 = gpt_uniform(r2);
+    if (OP == OP_LPDF_KVJP) {
+        P.kp.camp = gpt_uniform(amp * 4.0 * (PI_ / (2.0 * a.knu)) * a.kgamma);
+        P.kp.tn = gpt_uniform(2.0 / a.knu * PI_ * PI_);
+        P.kp.gco = gpt_uniform((a.knu + 1.0) * (4.0 * PI_ * PI_ / a.knu));
+        P.kp.m = __builtin_amdgcn_readfirstlane((int)(a.knu + 0.5));
+    } else {
+        P.kp.camp = gpt_uniform(amp * (2.0 * PI_));
+        P.kp.tn = 0.0;
+        P.kp.gco = 4.0 * PI_ * PI_;
+        P.kp.m = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -359,38 +426,46 @@ struct KernVal {
     double ck, f1, f2;
 };
 template <bool MATERN>
-__device__ __forceinline__ KernVal kern_eval(const LatArgs& a, const double* par, int i, int j) {
+__device__ __forceinline__ KernVal kern_eval(const LatArgs& a, const KernPre& kp, int i, int j) {
     constexpr double PI_ = 3.14159265358979323846;
-    const double sigma = par[0], l1 = par[1], l2 = par[2], p1 = par[3], p2 = par[4];
     const int ki = (i <= a.H / 2) ? i : a.H - i;
-    const double r1 = l1 / p1, r2 = l2 / p2; // uniform
-    const double a1 = (double)ki * r1, a2 = (double)j * r2;
+    const double a1 = (double)ki * kp.r1, a2 = (double)j * kp.r2;
     const double s1 = a1 * a1, s2 = a2 * a2;
-    const double amp = sigma * sigma * (double)a.H * (double)a.W * r1 * r2;
     KernVal v;
     if (!MATERN) {
-        v.ck = amp * (2.0 * PI_) * exp(-2.0 * PI_ * PI_ * (s1 + s2));
-        v.f1 = 4.0 * PI_ * PI_ * s1;
-        v.f2 = 4.0 * PI_ * PI_ * s2;
+        v.ck = kp.camp * exp(-2.0 * PI_ * PI_ * (s1 + s2));
+        v.f1 = kp.gco * s1;
+        v.f2 = kp.gco * s2;
         return v;
     }
-    const double tn = 2.0 / a.knu * PI_ * PI_; // uniform
-    const double arg = fma(tn, s1 + s2, 1.0);
-    const double inv = 1.0 / arg;
+    const double arg = fma(kp.tn, s1 + s2, 1.0); // >= 1
     // arg^-(nu + 1) for half-integer smoothness nu = m - 1/2, m = 1..6 (the reference's Python mirror allows 1.5 and
-    // 2.5 only, kernels.py:306): a square root and a few products; selects with
-    // trivial arms only (a nested choice of products became 32 branchy copies and 400 spilled registers). Other values never get
-    // here (gpt_api.hip composes them).
-    const int m = (int)(a.knu + 0.5);
+    // 2.5 only, kernels.py:306) is an odd power of y = arg^-1/2: one v_rsq_f64 with a third-order correction and a few
+    // products -- no division and no square root (the column pass of this op is bound by its arithmetic). Selects with
+    // trivial arms only (a nested choice of products became 32 branchy copies and 400 spilled registers). Other
+    // smoothness values never get here (gpt_api.hip composes them).
+    double y = __builtin_amdgcn_rsq(arg);
+    {
+        const double e = fma(-(arg * y), y, 1.0);
+        y = fma(y * e, fma(0.375, e, 0.5), y);
+    }
+    const double inv = y * y;
     const double i2 = inv * inv, i4 = i2 * i2;
-    const double t1 = (m & 1) ? inv : 1.0, t2 = (m & 2) ? i2 : 1.0, t4 = (m & 4) ? i4 : 1.0; // plain selects
-    const double im = t1 * t2 * t4;
-    const double pw = sqrt(inv) * im;
-    v.ck = amp * 4.0 * (PI_ / (2.0 * a.knu)) * a.kgamma * pw;
-    const double g = (a.knu + 1.0) * (4.0 * PI_ * PI_ / a.knu) * inv;
+    const double t1 = (kp.m & 1) ? inv : 1.0, t2 = (kp.m & 2) ? i2 : 1.0, t4 = (kp.m & 4) ? i4 : 1.0; // plain selects
+    v.ck = kp.camp * (y * (t1 * t2 * t4));
+    const double g = kp.gco * inv;
     v.f1 = g * s1;
     v.f2 = g * s2;
     return v;
+}
+// 1 / c for the kernel-fused ops (their column pass is bound by arithmetic): v_rcp_f64 + two Newton steps (<= 1 ulp)
+// for normal c, the bare hardware reciprocal for zero, denormal or non-finite c (the reference's c = 0 quirk, SURVEY
+// 8(a) quirk 1, keeps its inf / NaN downstream). 5 + 3 instructions instead of the 12 of the IEEE division.
+__device__ __forceinline__ double gpt_rcp_guarded(double c) {
+    const double r0 = __builtin_amdgcn_rcp(c); // (0 -> inf, inf -> 0, NaN -> NaN as they are)
+    double r = fma(fma(-c, r0, 1.0), r0, r0);
+    r = fma(fma(-c, r, 1.0), r, r);
+    return __builtin_amdgcn_class(c, 0x108 /* +-normal */) ? r : r0;
 }
 // cbar = d lpdf / d c at one entry -> the three sums
 __device__ __forceinline__ void acc_kern(EwAcc& acc, const KernVal& kv, double cbar) {
@@ -411,6 +486,12 @@ __device__ __forceinline__ cplx ew_interior_ic(const LatArgs& a, const ZLayout& 
     const double n = (double)a.H * (double)a.W;
     const unsigned iz = (unsigned)i * (unsigned)a.W;                // row offset into H x W arrays
     cplx ret = F;
+#ifdef GPT_TRAFFIC_ONLY
+#if GPT_TRAFFIC_ONLY
+    if (OP == OP_LPDF_VJP) P.out_cov[ic] = c;
+    return make_double2(F.x + c, F.y);
+#endif
+#endif
     if (OP == OP_RFFT2) {
         P.out_c[ic] = F;
         return ret;
@@ -420,7 +501,7 @@ __device__ __forceinline__ cplx ew_interior_ic(const LatArgs& a, const ZLayout& 
     }
     KernVal kv = {0.0, 0.0, 0.0};
     if (op_is_kvjp(OP)) { // `c` is not an input: the kernel is evaluated here
-        kv = kern_eval<OP == OP_LPDF_KVJP>(a, P.kpar, i, j);
+        kv = kern_eval<OP == OP_LPDF_KVJP>(a, P.kp, i, j);
         c = kv.ck + a.knugget;
     }
     acc.mn = fmin(acc.mn, 0.5 * n * c);
@@ -433,7 +514,7 @@ __device__ __forceinline__ cplx ew_interior_ic(const LatArgs& a, const ZLayout& 
         ret = make_double2(P.x[iz + L.re_col(j)] * s, P.x[iz + L.im_col(j)] * s);
     } else if (OP == OP_LPDF || op_is_lpdf_vjp(OP)) {
         const double f2 = fma(F.x, F.x, F.y * F.y);
-        const double inv_c = gpt_rcp(c);
+        const double inv_c = op_is_kvjp(OP) ? gpt_rcp_guarded(c) : gpt_rcp(c);
         const double q = f2 * inv_c * (1.0 / n); // |F|^2 / (n c); 1/n is uniform and hoisted: one division per
                                                  // element instead of two
         acc.sum -= q;
@@ -512,7 +593,7 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
     }
     KernVal kv = {0.0, 0.0, 0.0};
     if (op_is_kvjp(OP)) { // rows are mirrored in the kernel: the mirror row has the same value
-        kv = kern_eval<OP == OP_LPDF_KVJP>(a, P.kpar, k, j);
+        kv = kern_eval<OP == OP_LPDF_KVJP>(a, P.kp, k, j);
         c = cm = kv.ck + a.knugget;
     }
     if (real_pt) cm = c;

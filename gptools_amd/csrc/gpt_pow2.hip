@@ -117,21 +117,24 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
             e = by_size(a.H, [&](auto l) { return decltype(l)::col(op, a, ws, wstride, partials, nblk, edge_flags ? edge : nullptr, edge_flags, st); });
         if (e != hipSuccess) return e;
         // second reduction stage: folded into pass C when there is one
-        if (op_is_kvjp(op)) // four sums per lattice: their own reduction launch
-            return gpt_launch_finalize(partials, nblk, a.batch, 4, add, a.ksums, a.min_eig, st);
+        // (kernel-fused ops: the four sums per lattice are reduced and combined by pass C's workgroup 0 as well)
         if (reduces && !op_has_inv(op))
             e = gpt_launch_finalize(partials, nblk, a.batch, 1, add, lp ? a.out_lpdf : nullptr, a.min_eig, st);
         return e;
     }
     if (pass == 2) {
         if (!op_has_inv(op)) return hipSuccess;
-        FinArgs fin = {nullptr, 0, 0.0, nullptr, nullptr};
-        if (reduces && !op_is_kvjp(op)) {
+        FinArgs fin = {nullptr, 0, 0.0, nullptr, nullptr, nullptr, nullptr};
+        if (reduces) {
             fin.partials = partials;
             fin.nblk = nblk;
             fin.add = add;
             fin.out_sum = lp ? a.out_lpdf : nullptr;
             fin.out_min = a.min_eig;
+            if (op_is_kvjp(op)) {
+                fin.kpar = a.kpar;
+                fin.kbar = a.kbar;
+            }
         }
         double alpha = 1.0;
         int add_loc = 0;
@@ -163,7 +166,7 @@ hipError_t gpt_pow2_obs_rows(const LatArgs& a, cplx* ws, double* partials, int c
     if (R != 0 && R != 2) return hipErrorInvalidValue;
     if (R != (a.tw_sub ? gpt_pow2_sub_radix(OP_INV_VJP, a.H, a.W) : 0)) return hipErrorInvalidValue;
     const int nblk = R ? sub_col_blocks(R, a.H, a.W, col_cus) : whole_col_blocks(a.H, a.W, col_cus);
-    FinArgs fin = {partials, nblk, 0.0, nullptr, a.min_eig};
+    FinArgs fin = {partials, nblk, 0.0, nullptr, a.min_eig, nullptr, nullptr};
     double* edge = reinterpret_cast<double*>(ws + (size_t)a.batch * ws_spec_elems(a.H, a.W));
     const double alpha = 1.0 / ((double)a.H * (double)a.W);
     return by_size(a.W, [&](auto l) { return decltype(l)::row_obs(a, alpha, ws, wstride, fin, a.cov ? edge : nullptr, o, R == 2, st); });
@@ -298,7 +301,7 @@ hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, in
         return gpt_launch_finalize(partials, nblk, 1, 1, 0.0, a.out_lpdf, a.min_eig, st);
     }
     if (pass == 2) {
-        const FinArgs fin = {nullptr, 0, 0.0, nullptr, nullptr};
+        const FinArgs fin = {nullptr, 0, 0.0, nullptr, nullptr, nullptr, nullptr};
         return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, 0, spec, ld, fin, nullptr, false, st); });
     }
     return hipErrorInvalidValue;

@@ -34,6 +34,11 @@
 #ifndef GPT_ROWS_SAME
 #define GPT_ROWS_SAME 0
 #endif
+// Timing-only build (make traffic -> libvar_traffic.so, bench.py's roofline.three_pass_ceiling): the three passes with
+// every load and store of the real kernels and none of the arithmetic or LDS traffic between them. Results are garbage.
+#ifndef GPT_TRAFFIC_ONLY
+#define GPT_TRAFFIC_ONLY 0
+#endif
 #if GPT_TRACE
 // debug builds only (scripts/trace_col.py): phase timestamps (100 MHz clock) of wave 0 of every column workgroup
 __device__ unsigned long long g_col_trace[1024 * 8 * 8];
@@ -219,6 +224,9 @@ __device__ __forceinline__ void fft_rec(cplx (&v)[V][E], const int (&t)[V], doub
                                         const cplx (&wpre)[V][tw_npre<N>() > 0 ? tw_npre<N>() : 1]) {
     constexpr int R = stage_radix(N, NS);
     constexpr int U = E / R;
+#if GPT_TRAFFIC_ONLY
+    return;
+#endif
 #if GPT_TRACE
     constexpr int SIDX = NS == 1 ? 0 : (NS == 16 ? 1 : 2); // stage number (radix-16 plans)
     if (!INV && V > 1) TRACE_MARK(6, 2 * SIDX);
@@ -330,6 +338,9 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
     fft_regs<W, false>(v, t, lds, wpre);
     // split the two rows: need Z[j] (own registers) and Z[W - j] (through LDS, re then im)
     cplx zc[E / 2];
+#pragma unroll
+    for (int m = 0; m < E / 2; ++m) zc[m] = v[E - 1 - m]; // (what the timing-only build keeps)
+    if (!GPT_TRAFFIC_ONLY) {
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m].x;
@@ -347,6 +358,7 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_fwd_kernel(LatArgs a,
     for (int m = 0; m < E / 2; ++m) {
         const int j = t + T * m;
         zc[m].y = lds[phys(j == 0 ? 0 : W - j)];
+    }
     }
     if (!active) return;
     if (edge && a.cov && t == 0) {

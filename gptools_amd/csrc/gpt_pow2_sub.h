@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(THREADS, (V == 1 ? GPT_SUB_WPS1 : GPT_SUB_WPS2
     const int H = a.H;
     const ZLayout L = make_layout(a);
     EwPtrs P = make_ptrs(a, b);
+    kern_prepare<OP>(a, P);
     if (edge) {
         if (edge_flags & 1) P.edge_cov = edge + b * 4 * (int64_t)H;
         if (edge_flags & 2) P.edge_dcov = edge + b * 4 * (int64_t)H + 2 * (int64_t)H;

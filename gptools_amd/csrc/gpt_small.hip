@@ -29,7 +29,8 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
     const int64_t b = blockIdx.x;
     const int H = a.H, W = a.W;
     const ZLayout L = make_layout(a);
-    const EwPtrs P = make_ptrs(a, b);
+    EwPtrs P = make_ptrs(a, b);
+    kern_prepare<OP>(a, P);
     const int NC = 1 + L.wc;
     const int Hp = (H + 1) / 2;
     const bool weven = (W % 2) == 0;

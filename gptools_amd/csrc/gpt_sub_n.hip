@@ -1,6 +1,7 @@
 // Sub-line kernels (gpt_pow2_sub.h), one translation unit per line length: compiled with -DGPT_N=<power of two>.
 // GPT_N is the SUB-LINE length of colsub (and the line length of line_fft).
 #include "gpt_pow2_sub.h"
+#include <cstdlib>
 
 #ifndef GPT_N
 #error "compile with -DGPT_N=<power of two>"
@@ -76,11 +77,24 @@ template <int OP>
 static hipError_t colsub_t(const LatArgs& a, int R, cplx* ws, int wstride, const cplx* tws, double* partials, int nwg,
                            double* edge, int edge_flags, hipStream_t st) {
 #if GPT_N == 2048
+    // GPT_SUB_GEOM (tuning knob, same results): 1 = 256 threads (two workgroups per CU), 2 = the same with non-temporal
+    // workspace accesses, 3 = 512 threads with ordinary accesses, 4 = 512 threads non-temporal; 0 / unset = the rule below
+    static const int geom = [] {
+        const char* e = getenv("GPT_SUB_GEOM");
+        return e ? atoi(e) : 0;
+    }();
+    if (geom == 1) return colsub_g<OP, SUB_THREADS>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    if (geom == 2) return colsub_g<OP, SUB_THREADS, true>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    if (geom == 3) return colsub_g<OP, 512>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
+    if (geom == 4) return colsub_g<OP, 512, true>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
     // 512-thread workgroups (8 columns: whole 128-byte lines of the workspace, 64-byte pieces of cov) for the ops on
     // the real z layout, and for every op when the launch's workspace cannot be cache-resident (units of many
     // lattices, gpt_api.hip): 4096^2 column pass 124.5 -> 118 us there, but 123 -> 130 us on a warm workspace.
     const bool cold = (size_t)a.batch * (size_t)a.H * (size_t)wstride * sizeof(cplx) > ((size_t)256 << 20);
-    if (cold) // ... and streams the workspace past the caches
+    // (the kernel-fused ops load no cov and store no d/dcov: nothing of theirs comes in narrow pieces, and their
+    // arithmetic is what bounds them -- two small workgroups per CU overlap it with the workspace traffic:
+    // 4096^2 x 16 column pass 126 -> 105 us, profiles/r03_a_geom_ab.jsonl)
+    if (cold && !op_is_kvjp(OP)) // ... and streams the workspace past the caches
         return colsub_g<OP, 512, true>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
     if (op_z_layout(OP)) return colsub_g<OP, 512>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
 #endif

@@ -525,14 +525,17 @@ def _params(dim1, sigma, length_scale, period, device=None):
     return torch.stack(cols, dim=-1).contiguous(), tuple(bshape)
 
 
-def _lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget, dim1, check):
+def _lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget, dim1, check, out=None):
     g = _prep(y, loc, None, dim1)
     par, pshape = _params(dim1, sigma, length_scale, period, g["main"].device)
     if pshape != g["bshape"]:
         par = par.expand(*g["bshape"], par.shape[-1]).contiguous()
-    lp, mn = _new(g), _new(g)
-    gy = torch.empty_like(g["main"])
-    pbar = torch.empty_like(par)
+    if out is None:
+        lp, mn = _new(g), _new(g)
+        gy = torch.empty_like(g["main"])
+        pbar = torch.empty_like(par)
+    else:
+        lp, gy, pbar, mn = out
     get_context(lp.device).call("gpt_gp_rfft2_lpdf_kernel_vjp", int(kind != "expquad"), float(nu), _p(g["main"]),
                                 g["m_bs"], _p(g["loc"]), g["l_bs"], _p(par), float(nugget), g["H"], g["W"], g["B"],
                                 g["dim1"], _p(lp), _p(gy), _p(pbar), _p(mn))
@@ -542,10 +545,11 @@ def _lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget, dim1
     return lp, gy, (pbar[..., 0], pbar[..., 1:3], pbar[..., 3:5])
 
 
-def gp_rfft2_lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget=0.0, check=True):
+def gp_rfft2_lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget=0.0, check=True, out=None):
     """``gp_rfft2_lpdf(y | loc, kernel + nugget)`` (fft2.stan:189-192 over :206-247) without materialising the spectrum:
-    ``(lpdf, d/dy, (d/dsigma, d/dlength_scale, d/dperiod))``. ``kind``: ``"expquad"`` or ``"matern"`` (``nu``)."""
-    return _lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget, False, check)
+    ``(lpdf, d/dy, (d/dsigma, d/dlength_scale, d/dperiod))``. ``kind``: ``"expquad"`` or ``"matern"`` (``nu``).
+    ``out=(lpdf, grad_y, params_bar[..., 5], min_eig)`` reuses caller-owned output tensors (sampler / benchmark loops)."""
+    return _lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget, False, check, out)
 
 
 def gp_rfft_lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget=0.0, check=True):

@@ -117,3 +117,61 @@ def test_many_lattice_launch_rejects(fft):
     assert mn[11] == -0.5 * h * w * 2.0 and (np.delete(mn, 11) > 0).all()
     with pytest.raises(ValueError, match="not positive-definite"):
         fft.gp_rfft2_lpdf_vjp(y, None, cov)
+
+
+@pytest.mark.parametrize("kind,nu", [("matern", 1.5), ("expquad", 0.0)])
+def test_kernel_fused_many_lattice_launch(fft, kind, nu):
+    """The kernel-fused entry point (gpt_gp_rfft2_lpdf_kernel_vjp: fft2.stan:189-192 over :206-247 + nugget) on the
+    launch `bench.py` times for it: 16 lattices of 4096 x 4096 in one call, every lattice its own kernel parameters.
+    Lattices 0, 7 and 15 against the oracle's composition of the three reference functions and the chain rule at 1e-10;
+    every lattice against the library's own composition (spectrum kernel -> gp_rfft2_lpdf_vjp -> kernel reverse mode);
+    and with caller-owned outputs (`out=`), the form a sampler loop uses."""
+    import torch
+
+    h = w = 4096
+    batch = 16
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    loc = torch.randn(h, w, dtype=torch.float64, device=dev, generator=g)
+    y = loc + 0.7 * torch.randn(batch, h, w, dtype=torch.float64, device=dev, generator=g)
+    b = torch.arange(batch, dtype=torch.float64, device=dev)
+    sigma = 1.0 + 0.04 * b
+    ls = torch.stack([6.0 + 0.5 * b, 14.0 - 0.3 * b], dim=-1)
+    per = torch.stack([float(h) * (1.0 + 0.01 * b), float(w) * (1.1 - 0.01 * b)], dim=-1)
+    eps = 1e-3
+    lp, gy, (sb, lb, pb) = fft.gp_rfft2_lpdf_kernel_vjp(y, loc, kind, nu, sigma, ls, per, nugget=eps)
+    assert lp.shape == (batch,) and gy.shape == y.shape and lb.shape == (batch, 2) and pb.shape == (batch, 2)
+    loc_h = loc.cpu().numpy()
+    for i in (0, 7, 15):
+        s_i, l_i, p_i = float(sigma[i]), ls[i].cpu().numpy(), per[i].cpu().numpy()
+        cov = (o.gp_periodic_exp_quad_cov_rfft2(h, w, s_i, l_i, p_i) if kind == "expquad"
+               else o.gp_periodic_matern_cov_rfft2(nu, h, w, s_i, l_i, p_i)) + eps
+        lp_o, gy_o, gc_o = o.gp_rfft2_lpdf_vjp(y[i].cpu().numpy(), loc_h, cov)
+        bars = (o.gp_periodic_exp_quad_cov_rfft2_vjp(h, w, s_i, l_i, p_i, gc_o) if kind == "expquad"
+                else o.gp_periodic_matern_cov_rfft2_vjp(nu, h, w, s_i, l_i, p_i, gc_o))
+        _close(lp[i], lp_o, RTOL, f"lpdf of lattice {i}")
+        _close(gy[i], gy_o, RTOL, f"d/dy of lattice {i}")
+        # sums of ~n terms of both signs: tolerance relative to the sum of magnitudes
+        scale = float(np.abs(gc_o * cov).sum())
+        for got, want, p, what in zip((sb[i], lb[i], pb[i]), bars, (s_i, l_i, p_i), ("sigma", "length_scale", "period")):
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-9, atol=1e-10 * scale / float(np.min(np.abs(p))),
+                                       err_msg=f"d/d{what} of lattice {i}")
+    # every lattice against the library's own composition, four lattices at a time
+    for i0 in range(0, batch, 4):
+        sl = slice(i0, i0 + 4)
+        cov = (fft.gp_periodic_exp_quad_cov_rfft2(h, w, sigma[sl], ls[sl], per[sl]) if kind == "expquad"
+               else fft.gp_periodic_matern_cov_rfft2(nu, h, w, sigma[sl], ls[sl], per[sl])) + eps
+        lp_c, gy_c, gc_c = fft.gp_rfft2_lpdf_vjp(y[sl], loc, cov)
+        _close(lp[sl], lp_c, 1e-12, f"lpdf of lattices {i0}.. vs composition")
+        _close(gy[sl], gy_c, 1e-12, f"d/dy of lattices {i0}.. vs composition")
+        del cov, lp_c, gy_c, gc_c
+    # caller-owned outputs
+    out = (torch.empty_like(lp), torch.empty_like(gy), torch.empty(batch, 5, dtype=torch.float64, device=dev),
+           torch.empty_like(lp))
+    lp2, gy2, (sb2, lb2, pb2) = fft.gp_rfft2_lpdf_kernel_vjp(y, loc, kind, nu, sigma, ls, per, nugget=eps, out=out)
+    assert lp2.data_ptr() == out[0].data_ptr() and gy2.data_ptr() == out[1].data_ptr()
+    assert torch.equal(lp2, lp) and torch.equal(gy2, gy) and torch.equal(sb2, sb) and torch.equal(lb2, lb)
+    assert torch.equal(pb2, pb)
+    del out, gy2, gy
+    torch.cuda.empty_cache()
