@@ -85,6 +85,8 @@ _PLAIN = {
     "gpt_profile_begin": ([c_ptr], c_int),
     "gpt_profile_end": ([c_ptr, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)], c_int),
     "gpt_path_for_shape": ([c_i64, c_i64], c_int),
+    "gpt_host_copy_slice": ([ctypes.c_size_t, c_int, c_int, ctypes.POINTER(ctypes.c_size_t),
+                             ctypes.POINTER(ctypes.c_size_t)], None),
     # cross-chain batching
     "gpt_batcher_create": ([c_int, c_int, c_int, c_i64, c_i64, c_int, ctypes.POINTER(c_ptr)], c_int),
     "gpt_batcher_destroy": ([c_ptr], c_int),

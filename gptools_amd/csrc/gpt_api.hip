@@ -20,6 +20,17 @@
 // copies at ~20 GB/s. Large arrays go through a ring of pinned bounce buffers instead: a few worker threads copy chunk
 // k + 1 between the caller's memory and a pinned buffer while the DMA engine moves chunk k, so a transfer runs at what
 // PCIe gives. Owned by a context (one calling thread at a time); small arrays keep the plain path.
+// Slice `id` of `nt` of an n-byte copy: ceil(n / nt) rounded up to a page, the last slices shortened or empty, so that
+// the slices tile [0, n) exactly for every n and nt (round 2 rounded floor(n / nt) up and lost the last n % nt bytes
+// when that was already a multiple of 4096 and nt >= 9). Exported for its unit test (tests/test_host_copy_slices.py).
+extern "C" void gpt_host_copy_slice(size_t n, int nt, int id, size_t* lo, size_t* len) {
+    if (nt < 1) nt = 1;
+    const size_t slice = (((n + (size_t)nt - 1) / (size_t)nt) + 4095) & ~(size_t)4095;
+    const size_t a = (size_t)id * slice;
+    *lo = a < n ? a : n;
+    *len = a < n ? (a + slice <= n ? slice : n - a) : 0;
+}
+
 struct HostPipe {
     static constexpr size_t CHUNK = (size_t)8 << 20;
     static constexpr int NBUF = 4;
@@ -80,10 +91,10 @@ struct HostPipe {
             memcpy(dst, src, n);
             return;
         }
-        const size_t slice = ((n / nt) + 4095) & ~(size_t)4095;
         auto part = [=](int id) {
-            const size_t lo = (size_t)id * slice;
-            if (lo < n) memcpy(dst + lo, src + lo, (lo + slice <= n) ? slice : n - lo);
+            size_t lo = 0, len = 0;
+            gpt_host_copy_slice(n, nt, id, &lo, &len);
+            if (len) memcpy(dst + lo, src + lo, len);
         };
         {
             std::lock_guard<std::mutex> lk(m);
@@ -596,6 +607,9 @@ int gpt_create(int device, void* stream, gpt_ctx** out) {
 
 int gpt_destroy(gpt_ctx* c) {
     if (!c) return GPT_OK;
+    // (may run on whichever thread collects the context, e.g. a finalizer: leave that thread's current device alone)
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& r : c->prof) {
@@ -618,6 +632,7 @@ int gpt_destroy(gpt_ctx* c) {
     if (c->bounce) (void)hipHostFree(c->bounce);
     gpt_anyn_destroy(c->anyn);
     delete c;
+    if (prev >= 0) (void)hipSetDevice(prev);
     return GPT_OK;
 }
 
@@ -1027,7 +1042,10 @@ int gpt_gp_rfft2_lpdf_vjp_noalloc(gpt_ctx* c, const double* y, int64_t y_bs, con
     };
     const char* too_big = "this lattice needs more than the 40 MiB of built-in scratch of the allocation-free entry point "
                           "(three-pass lattices up to 2048 x 2048); use gpt_gp_rfft2_lpdf_vjp";
-    if (path == 3) return fail(c, GPT_ERR_UNSUPPORTED, too_big); // (the any-length path allocates its plans and scratch)
+    if (path == 3) // (its plans, tables and Bluestein scratch are allocated per shape)
+        return fail(c, GPT_ERR_UNSUPPORTED,
+                    "the allocation-free entry point does not take any-length shapes (long, prime or non-power-of-two "
+                    "axes beyond 4096 points: their line plans and scratch are allocated); use gpt_gp_rfft2_lpdf_vjp");
     if ((rc = plan_radices(c, a.W, a.pw)) != GPT_OK || (rc = plan_radices(c, a.H, a.ph)) != GPT_OK) return rc;
     if ((rc = table(a.W, &a.pw.tw)) != GPT_OK) return fits ? rc : fail(c, GPT_ERR_UNSUPPORTED, too_big);
     if (a.H == a.W) a.ph.tw = a.pw.tw;

@@ -35,6 +35,7 @@
 #ifndef GPTOOLS_HIP_H
 #define GPTOOLS_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -70,6 +71,9 @@ const char* gpt_version(void);
  * second reduction stage), and the number of column-pass launches they were summed over. */
 int gpt_profile_begin(gpt_ctx* ctx);
 int gpt_profile_end(gpt_ctx* ctx, double* pass_ms, int64_t* launches);
+/* Test aid (no counterpart in the reference; host arithmetic only): how the pinned staging ring of the *_host entry
+ * points splits an n-byte copy over nt threads -- slice `id` is [*lo, *lo + *len). The slices tile [0, n) exactly. */
+void gpt_host_copy_slice(size_t n, int nt, int id, size_t* lo, size_t* len);
 /* Which kernel family a lattice shape runs on: 0 small (one workgroup per lattice, any H/W),
  * 1 power-of-two three-pass, 2 generic three-pass, 3 any-length (axes of up to 2^23 points by four-step and
  * Bluestein line transforms: long 1-D series, util.stan:263-265 takes any n), -1 unsupported. */

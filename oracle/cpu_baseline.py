@@ -83,16 +83,19 @@ def main():
     evals = max(1, min(4, int(a.budget / (1.5 * per_eval))))
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(procs) as pool:
-        pool.map(_worker, [(size, 100 + p, evals) for p in range(procs)])
+        worker_s = pool.map(_worker, [(size, 100 + p, evals) for p in range(procs)])
     el_all = time.perf_counter() - t0  # includes start-up and input generation: a job's view
+    el_eval = max(worker_s)            # the evaluations alone, as the GPU figure counts them (slowest process)
     print(json.dumps({
-        "value": procs * evals / el_all,
+        "value": procs * evals / el_eval,
         "unit": "evals/s",
         "cores": procs,
         "kind": "port",
         "kind_note": "build restatement (oracle/gp_oracle.py, NumPy pocketfft) -- cmdstan unavailable",
-        "sample": f"{procs} processes x {evals} evaluations of gp_rfft2_lpdf+grad at {size}x{size} in {el_all:.1f} s "
-                  "(process start-up and input generation included)",
+        "sample": f"{procs} processes x {evals} evaluations of gp_rfft2_lpdf+grad at {size}x{size}; the slowest process "
+                  f"spent {el_eval:.1f} s evaluating (inputs resident, as for the GPU figure); wall clock with process "
+                  f"start-up and input generation {el_all:.1f} s",
+        "value_wall": procs * evals / el_all,
         "one_core": {"value": n1 / el1, "cores": 1,
                      "sample": f"{n1} evaluations in {el1:.1f} s, single thread"},
         "nproc": os.cpu_count(),

@@ -93,6 +93,58 @@ def test_noalloc_matches_existing_entry_point(fft, first, second):
     _compare(outs3, f"third call {second} without d/dcov and loc")
 
 
+def test_noalloc_allocates_nothing_on_a_fresh_context(fft):
+    """On a context that has run nothing else (no cached workspace, partials or twiddle tables), the entry point is
+    called FIRST and repeatedly: the device's free memory does not move (hipMemGetInfo through torch), the context's
+    cached buffers stay empty, and the results equal the allocating entry point's (called afterwards)."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    h, w, batch = 1024, 512, 6
+    # (in a fresh process the very first launch loads the library's code object, which moves the device's free memory:
+    # one throw-away call on a throw-away context takes that out of the measurement)
+    fft.close_contexts()
+    warm = fft.get_context(dev)
+    t = torch.ones(1, h, w, dtype=torch.float64, device=dev)
+    tc = torch.ones(1, h, w // 2 + 1, dtype=torch.float64, device=dev)
+    tl = torch.empty(1, dtype=torch.float64, device=dev)
+    warm.call("gpt_gp_rfft2_lpdf_vjp_noalloc", t.data_ptr(), h * w, None, 0, tc.data_ptr(), h * (w // 2 + 1), h, w, 1, 0,
+              tl.data_ptr(), torch.empty_like(t).data_ptr(), None, None)
+    torch.cuda.synchronize()
+    fft.close_contexts()
+    ctx = fft.get_context(dev)  # gpt_create: resolves the built-in array; allocates one pinned page
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    y = torch.randn(batch, h, w, dtype=torch.float64, device=dev, generator=g)
+    loc = torch.randn(h, w, dtype=torch.float64, device=dev, generator=g)
+    cov = torch.exp(0.3 * torch.randn(batch, h, w // 2 + 1, dtype=torch.float64, device=dev, generator=g))
+    outs = []
+    for _ in range(2):
+        outs.append((torch.empty(batch, dtype=torch.float64, device=dev), torch.empty_like(y), torch.empty_like(cov),
+                     torch.empty(batch, dtype=torch.float64, device=dev)))
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+
+    def call(name, o_):
+        ctx.call(name, y.data_ptr(), h * w, loc.data_ptr(), 0, cov.data_ptr(), h * (w // 2 + 1), h, w, batch, 0,
+                 o_[0].data_ptr(), o_[1].data_ptr(), o_[2].data_ptr(), o_[3].data_ptr())
+        torch.cuda.synchronize()
+
+    for _ in range(3):
+        call("gpt_gp_rfft2_lpdf_vjp_noalloc", outs[0])
+        free1, _ = torch.cuda.mem_get_info(dev)
+        assert free1 == free0, f"device free memory moved by {free0 - free1} bytes across an allocation-free call"
+    call("gpt_gp_rfft2_lpdf_vjp", outs[1])  # this one allocates workspace, partials and tables
+    free2, _ = torch.cuda.mem_get_info(dev)
+    assert free2 < free0
+    _compare([outs[1], outs[0]], "fresh context")
+    with pytest.raises(NotImplementedError, match="any-length"):
+        yy = torch.zeros(1, 6, 5000, dtype=torch.float64, device=dev)
+        cc = torch.ones(1, 6, 2501, dtype=torch.float64, device=dev)
+        ctx.call("gpt_gp_rfft2_lpdf_vjp_noalloc", yy.data_ptr(), 30000, None, 0, cc.data_ptr(), 6 * 2501, 6, 5000, 1, 0,
+                 outs[0][0].data_ptr(), torch.empty_like(yy).data_ptr(), None, None)
+
+
 def test_noalloc_rejects_what_does_not_fit(fft):
     import torch
 
