@@ -7,6 +7,7 @@ header ``include/gptools_hip.hpp`` that binds the Stan functions to ``libgptools
 cmdstanpy/cmdstan are not part of this build image; importing this module works without them and the
 functions raise an informative error if they are called without cmdstanpy.
 """
+import logging
 import os
 from typing import Any, Dict, Optional, Type, Union
 
@@ -17,6 +18,18 @@ _ROOT = os.path.dirname(os.path.dirname(_HERE))
 def get_include() -> str:
     """Directory that holds ``gptools/fft.stan`` etc. (same contract as the reference's get_include)."""
     return _HERE
+
+
+def set_cmdstanpy_log_level(level: Optional[Union[str, int]] = None) -> None:
+    """Set the level of every handler of cmdstanpy's logger (reference ``__init__.py:26-35``); ``None`` means
+    ``WARNING``."""
+    try:
+        import cmdstanpy
+    except ImportError as exc:  # pragma: no cover - cmdstanpy is absent from the build image
+        raise ImportError("gptools_amd.stan.set_cmdstanpy_log_level needs cmdstanpy") from exc
+    target = logging.WARNING if level is None else level
+    for handler in cmdstanpy.utils.get_logger().handlers:
+        handler.setLevel(target)
 
 
 def get_user_header() -> str:
@@ -69,3 +82,10 @@ def compile_model(
         user_header=user_header or get_user_header(),
         **kwargs,
     )
+
+
+if os.environ.get("READTHEDOCS"):  # as the reference does at import time (python/stan/gptools/stan/__init__.py:93-94)
+    try:
+        set_cmdstanpy_log_level("ERROR")
+    except ImportError:  # pragma: no cover
+        pass

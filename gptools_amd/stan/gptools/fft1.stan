@@ -6,7 +6,7 @@ vector gp_unpack_rfft(complex_vector x, int n);
 vector gp_rfft(vector y, vector loc, vector cov_rfft);
 real gp_rfft_log_abs_det_jac(vector cov_rfft, int n);
 real gp_rfft_log_abs_det_jacobian(vector cov_rfft, int n) {
-    reject("`gp_rfft_log_abs_det_jacobian` has been renamed to `gp_rfft_log_abs_det_jac`.");
+    reject("`gp_rfft_log_abs_det_jacobian` has been renamed to `gp_rfft_log_abs_det_jac` to comply with upcoming changes (see https://github.com/stan-dev/stanc3/issues/1470 for details).");
 }
 real gp_rfft_lpdf(vector y, vector loc, vector cov_rfft);
 complex_vector gp_pack_rfft(vector z);
