@@ -103,6 +103,21 @@ def spawn_ranks(n, argv):
     sys.exit(0)
 
 
+def matern_cov_columns(nu, h, w, sigma, length_scale, col0, ncols, device):
+    """Synthetic input of the slab bench: columns col0 .. col0 + ncols - 1 of gp_periodic_matern_cov_rfft2(nu, h, w, sigma,
+    length_scale, period = (h, w)) (fft2.stan:228-247; closed form SURVEY 8(a)) as an (h, ncols) array, without the rest of
+    the spectrum. tests/test_gpu_slab.py holds it to the library's kernel."""
+    import math
+
+    ki = torch.arange(h, dtype=torch.float64, device=device)
+    ki = torch.minimum(ki, h - ki)
+    j = torch.arange(col0, col0 + ncols, dtype=torch.float64, device=device)
+    r1, r2 = length_scale[0] / h, length_scale[1] / w
+    arg = 1.0 + (2.0 / nu) * math.pi ** 2 * ((ki * r1)[:, None] ** 2 + (j * r2)[None, :] ** 2)
+    amp = sigma ** 2 * h * w * 4.0 * (math.pi / (2.0 * nu)) * math.gamma(nu + 1.0) / math.gamma(nu) * r1 * r2
+    return amp * arg ** (-(nu + 1.0))
+
+
 def slab_bench(args, fft, device, world, rank, distributed):
     """One lattice over all ranks; a step is one evaluation of gp_rfft2_lpdf + gradients."""
     import torch.distributed as dist
@@ -112,24 +127,27 @@ def slab_bench(args, fft, device, world, rank, distributed):
     h = w = args.size
     rows, nc = slab.slab_shapes(h, w, world)
     comm = slab.DistComm() if distributed else slab.SingleComm()
-    cov = fft.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.3, [8.0, 12.0], [float(h), float(w)]) + 1e-3
+    stages = slab.HipStages(buffers=slab.SlabBuffers())  # exchange and output buffers allocated once, not per step
     g = torch.Generator(device=device)
     g.manual_seed(11 + rank)
     loc = torch.randn(rows, w, dtype=torch.float64, device=device, generator=g)
     y = loc + torch.randn(rows, w, dtype=torch.float64, device=device, generator=g)
-    if world > 1:  # a rank keeps only its own columns of the spectrum (and of d/dcov)
-        cov_cols, cov_nyq = slab.own_columns(cov, rank, world)
-        del cov
-        torch.cuda.empty_cache()
+    if world > 1 or os.environ.get("GPT_BENCH_FORCE_NCCL"):
+        # a rank holds only its own columns of the spectrum (and of d/dcov), generated in that layout:
+        # the whole H x (W/2 + 1) array (4 GiB at 32768^2) never exists on any rank
+        cov_cols = matern_cov_columns(1.5, h, w, 1.3, (8.0, 12.0), rank * nc, nc, device) + 1e-3
+        cov_nyq = (matern_cov_columns(1.5, h, w, 1.3, (8.0, 12.0), w // 2, 1, device)[:, 0] + 1e-3) if rank == 0 else None
 
         def step():
-            lp_, gy_, mn_, _, _ = slab.gp_rfft2_lpdf_vjp_slab_owned(y, loc, cov_cols, cov_nyq, h, w, comm=comm)
+            lp_, gy_, mn_, _, _ = slab.gp_rfft2_lpdf_vjp_slab_owned(y, loc, cov_cols, cov_nyq, h, w, comm=comm,
+                                                                    stages=stages, chunks=args.chunks or None)
             return lp_, gy_, mn_
     else:
+        cov = fft.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.3, [8.0, 12.0], [float(h), float(w)]) + 1e-3
         out_cov = torch.empty(h, w // 2 + 1, dtype=torch.float64, device=device)
 
         def step():
-            return slab.gp_rfft2_lpdf_vjp_slab(y, loc, cov, h, w, comm=comm, out_cov=out_cov)
+            return slab.gp_rfft2_lpdf_vjp_slab(y, loc, cov, h, w, comm=comm, stages=stages, out_cov=out_cov)
 
     def barrier():
         if distributed:
@@ -156,7 +174,9 @@ def slab_bench(args, fft, device, world, rank, distributed):
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"one synthetic {h}x{w} lattice, {rows} rows and {nc} packed columns per rank, "
                                    "two all-to-all exchanges per evaluation",
-                       "parallelism": f"slab decomposition over {world} GPU(s)"},
+                       "parallelism": f"slab decomposition over {world} GPU(s)",
+                       "exchange": (f"torch.distributed {dist.get_backend()} process group" if distributed
+                                    else "none (one rank, no process group)")},
             "roofline": {"bound": "hbm", "achieved": b_alg * args.steps / elapsed / 1e9 / world,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": b_alg * args.steps / elapsed / world / HBM_PEAK, "traffic": None,
@@ -338,6 +358,7 @@ def main():
     ap.add_argument("--slab", action="store_true",
                     help="not the headline: ONE lattice of --size split over all ranks (row / column slabs, "
                          "all-to-all over RCCL), strong scaling")
+    ap.add_argument("--chunks", type=int, default=0, help="--slab: row chunks per exchange (0: 4 with peers, else 1)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-pass HIP-event timing")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra (non-headline) kernel-fused measurement")
     ap.add_argument("--no-ceiling", action="store_true",
@@ -361,11 +382,17 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if args.dry_run:
         return dry_run(args, world, rank)
-    distributed = world > 1
+    # GPT_BENCH_FORCE_NCCL=1: a one-rank job still goes through an RCCL process group (the only way to put the nccl
+    # branch -- group set-up, the max-over-ranks all-reduce, the slab exchanges -- on hardware with one GPU)
+    distributed = world > 1 or bool(os.environ.get("GPT_BENCH_FORCE_NCCL"))
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # rehearsal on a one-GPU box: GPT_BENCH_REHEARSAL=1 puts every rank on device 0 and uses gloo
         if os.environ.get("GPT_BENCH_REHEARSAL"):
             local_rank = 0

@@ -28,14 +28,40 @@ import torch
 from . import fft as _fft
 
 
+class SlabBuffers:
+    """Exchange and output buffers of a slab evaluation, allocated once per shape and handed out again on every later
+    call (a sampler evaluates the same lattice thousands of times). With buffers, the tensors an evaluation returns are
+    these buffers: they are valid until the next evaluation that uses the same `SlabBuffers`."""
+
+    def __init__(self):
+        self._t = {}
+
+    def get(self, name, shape, dtype, device):
+        key = (name, tuple(int(s) for s in shape), dtype, str(device))
+        t = self._t.get(key)
+        if t is None:
+            t = self._t[key] = torch.empty(key[1], dtype=dtype, device=device)
+        return t
+
+
+def _empty(stages, name, shape, dtype, device):
+    """A buffer from the stages' `SlabBuffers` when they have one, a fresh tensor otherwise."""
+    pool = getattr(stages, "buffers", None)
+    return pool.get(name, shape, dtype, device) if pool is not None else torch.empty(tuple(shape), dtype=dtype, device=device)
+
+
 class HipStages:
     """The three local passes on the GPU (device tensors, the context's stream), on the layouts of the exchange: the row
     passes write / read the (ranks, rows, columns per rank) buffers the all-to-all sends and receives, the column pass
-    works on the rank's own columns of cov and d/dcov."""
+    works on the rank's own columns of cov and d/dcov. `buffers`: a `SlabBuffers` to allocate everything once per shape
+    (bench.py --slab, sampler loops); None allocates per call."""
 
-    def rows_fwd_blocked(self, y_rows, loc_rows, height, width, world):
+    def __init__(self, buffers=None):
+        self.buffers = buffers
+
+    def rows_fwd_blocked(self, y_rows, loc_rows, height, width, world, tag=0):
         rows, nc = y_rows.shape[0], width // 2 // world
-        send = torch.empty(world, rows, nc, dtype=torch.complex128, device=y_rows.device)
+        send = _empty(self, f"send{tag}", (world, rows, nc), torch.complex128, y_rows.device)
         ctx = _fft.get_context(y_rows.device)
         ctx.call("gpt_slab_rows_fwd_blocked", _fft._p(y_rows), _fft._p(loc_rows), rows, height, width, _fft._p(send), nc)
         return send
@@ -46,12 +72,12 @@ class HipStages:
         column W/2 or None)."""
         ncols = spec_cols.shape[1]
         dev = spec_cols.device
-        lp = torch.empty(1, dtype=torch.float64, device=dev)
-        mn = torch.empty(1, dtype=torch.float64, device=dev)
-        out_cols = torch.empty_like(cov_cols) if need_cov_grad else None
+        lp = _empty(self, "lp", (1,), torch.float64, dev)
+        mn = _empty(self, "mn", (1,), torch.float64, dev)
+        out_cols = _empty(self, "out_cols", cov_cols.shape, torch.float64, dev) if need_cov_grad else None
         edge = None
         if col0 == 0:
-            edge = torch.empty(4, height, dtype=torch.float64, device=dev)
+            edge = _empty(self, "edge", (4, height), torch.float64, dev)
             edge[0].copy_(cov_cols[:, 0])
             edge[1].copy_(cov_nyquist)
         ctx = _fft.get_context(dev)
@@ -60,13 +86,14 @@ class HipStages:
         out_nyq = None
         if col0 == 0 and need_cov_grad:
             out_cols[:, 0].copy_(edge[2])
-            out_nyq = edge[3].clone()
+            out_nyq = _empty(self, "out_nyq", (height,), torch.float64, dev)
+            out_nyq.copy_(edge[3])
         return lp, mn, out_cols, out_nyq
 
     def rows_inv_blocked(self, recv, height, width, alpha, out=None):
         world, rows, nc = recv.shape
         if out is None:
-            out = torch.empty(rows, width, dtype=torch.float64, device=recv.device)
+            out = _empty(self, "grad_rows", (rows, width), torch.float64, recv.device)
         ctx = _fft.get_context(recv.device)
         ctx.call("gpt_slab_rows_inv_blocked", _fft._p(recv), nc, rows, height, width, float(alpha), _fft._p(out))
         return out
@@ -100,10 +127,10 @@ class HipStages:
         """All three passes on one device (world size 1): no exchange, and the spectrum rows are padded by 8 columns
         so that the column pass does not walk a power-of-two stride."""
         ld = width // 2 + 8
-        spec = torch.empty(height, ld, dtype=torch.complex128, device=y.device)
-        lp = torch.empty(1, dtype=torch.float64, device=y.device)
-        mn = torch.empty(1, dtype=torch.float64, device=y.device)
-        out = torch.empty(height, width, dtype=torch.float64, device=y.device)
+        spec = _empty(self, "spec", (height, ld), torch.complex128, y.device)
+        lp = _empty(self, "lp", (1,), torch.float64, y.device)
+        mn = _empty(self, "mn", (1,), torch.float64, y.device)
+        out = _empty(self, "grad_rows", (height, width), torch.float64, y.device)
         ctx = _fft.get_context(y.device)
         ctx.call("gpt_slab_rows_fwd", _fft._p(y), _fft._p(loc), height, height, width, _fft._p(spec), ld)
         ctx.call("gpt_slab_cols_lpdf_vjp", _fft._p(spec), ld, _fft._p(cov), _fft._p(out_cov), height, width, 0,
@@ -286,12 +313,15 @@ def gp_rfft2_lpdf_vjp_slab_owned(y_rows, loc_rows, cov_cols, cov_nyquist, height
         cols = comm.all_to_all(send).reshape(height, nc)                                  # all rows, my columns
     else:
         rc = rows // nchunk
-        cols = torch.empty(height, nc, dtype=torch.complex128, device=y_rows.device)
+        cols = _empty(stages, "cols", (height, nc), torch.complex128, y_rows.device)
         cols3 = cols.view(world, rows, nc)                                                # block p: rank p's rows
         pending = []
+        tagged = isinstance(stages, HipStages)  # (the tests' own stages keep the three-argument form)
         for k in range(nchunk):
             r0 = k * rc
-            send = stages.rows_fwd_blocked(y_rows[r0:r0 + rc], loc_rows[r0:r0 + rc], height, width, world)  # (G, rc, nc)
+            send = (stages.rows_fwd_blocked(y_rows[r0:r0 + rc], loc_rows[r0:r0 + rc], height, width, world, tag=k)
+                    if tagged else
+                    stages.rows_fwd_blocked(y_rows[r0:r0 + rc], loc_rows[r0:r0 + rc], height, width, world))  # (G, rc, nc)
             work = comm.all_to_all_start(list(send.unbind(0)), [cols3[p, r0:r0 + rc] for p in range(world)])
             pending.append((work, send))                                                  # (send stays alive until waited for)
         for work, _ in pending:
@@ -303,11 +333,11 @@ def gp_rfft2_lpdf_vjp_slab_owned(y_rows, loc_rows, cov_cols, cov_nyquist, height
         grad_rows = stages.rows_inv_blocked(back, height, width, -1.0 / n)
     else:
         cols3 = cols.view(world, rows, nc)
-        grad_rows = torch.empty(rows, width, dtype=torch.float64, device=y_rows.device)
+        grad_rows = _empty(stages, "grad_rows", (rows, width), torch.float64, y_rows.device)
         pending = []
         for k in range(nchunk):
             r0 = k * rc
-            back = torch.empty(world, rc, nc, dtype=torch.complex128, device=y_rows.device)
+            back = _empty(stages, f"back{k}", (world, rc, nc), torch.complex128, y_rows.device)
             work = comm.all_to_all_start([cols3[p, r0:r0 + rc] for p in range(world)], list(back.unbind(0)))
             pending.append((work, back))
         for k, (work, back) in enumerate(pending):

@@ -255,3 +255,83 @@ def test_slab_two_processes_through_torch_distributed():
         np.testing.assert_allclose(lp, lp_ref, rtol=RTOL)
         np.testing.assert_allclose(gy, gy_ref[rank * rows:(rank + 1) * rows], rtol=RTOL, atol=RTOL * np.abs(gy_ref).max())
         np.testing.assert_allclose(mn, 0.5 * h * w * cov.min(), rtol=1e-13)
+
+
+def _rccl_worker(port, h, w, chunks, q):
+    """One rank, but a real RCCL process group: group set-up on the GPU, the list-form asynchronous all-to-all of the
+    chunked exchange, all_to_all_single (unchunked), and both scalar all-reduces all execute through RCCL."""
+    import torch.distributed as dist
+
+    from gptools_amd import slab
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        y, loc, cov = _dist_inputs(h, w)
+        covd = torch.from_numpy(cov).to(dev)
+        cols, nyq = slab.own_columns(covd, 0, 1)
+        yd, ld = torch.from_numpy(y).to(dev), torch.from_numpy(loc).to(dev)
+        comm = slab.DistComm()
+        out = {}
+        stages = slab.HipStages(buffers=slab.SlabBuffers())
+        for name, ch, st in (("chunked", chunks, None), ("single", 1, None), ("pooled", chunks, stages), ("pooled2", chunks, stages)):
+            lp, gy, mn, dcols, dnyq = slab.gp_rfft2_lpdf_vjp_slab_owned(yd, ld, cols, nyq, h, w, comm=comm, chunks=ch, stages=st)
+            torch.cuda.synchronize()
+            out[name] = (float(lp), gy.cpu().numpy(), float(mn), dcols.cpu().numpy(), dnyq.cpu().numpy())
+        t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the bench's max-over-ranks clock
+        dist.barrier()
+        q.put((out, float(t)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slab_one_rank_rccl_process_group():
+    """RCCL on hardware with the one GPU this box has (missing 1): a one-rank nccl process group runs the slab
+    evaluation with 4 row chunks per exchange (list-form asynchronous all_to_all on RCCL's stream, overlapped with the row
+    kernels), unchunked (all_to_all_single), and with pooled buffers twice in a row; all against the oracle at 1e-10."""
+    import socket
+
+    import gp_oracle as oracle
+    import torch.multiprocessing as mp
+
+    h, w = 1024, 1024
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, h, w, 4, q))
+    p.start()
+    out, tmax = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and tmax == 3.5
+    y, loc, cov = _dist_inputs(h, w)
+    lp_ref, gy_ref, gc_ref = oracle.gp_rfft2_lpdf_vjp(y, loc, cov)
+    for name, (lp, gy, mn, dcols, dnyq) in out.items():
+        np.testing.assert_allclose(lp, lp_ref, rtol=RTOL, err_msg=name)
+        np.testing.assert_allclose(gy, gy_ref, rtol=RTOL, atol=RTOL * np.abs(gy_ref).max(), err_msg=name)
+        np.testing.assert_allclose(mn, 0.5 * h * w * cov.min(), rtol=1e-13, err_msg=name)
+        np.testing.assert_allclose(dcols, gc_ref[:, :w // 2], rtol=RTOL, atol=RTOL * np.abs(gc_ref).max(), err_msg=name)
+        np.testing.assert_allclose(dnyq, gc_ref[:, w // 2], rtol=RTOL, atol=RTOL * np.abs(gc_ref).max(), err_msg=name)
+
+
+def test_bench_slab_spectrum_columns_match_the_kernel():
+    """bench.py --slab generates each rank's columns of the Matern spectrum directly; they are the library's."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from gptools_amd import fft
+
+    dev = torch.device("cuda", 0)
+    h, w = 512, 1024
+    full = fft.gp_periodic_matern_cov_rfft2(1.5, h, w, 1.3, [8.0, 12.0], [float(h), float(w)])
+    for col0, nc in ((0, 128), (384, 128), (w // 2, 1)):
+        got = bench.matern_cov_columns(1.5, h, w, 1.3, (8.0, 12.0), col0, nc, dev)
+        torch.testing.assert_close(got, full[:, col0:col0 + nc], rtol=1e-12, atol=0.0)
