@@ -184,8 +184,6 @@ struct gpt_ctx {
     size_t kscr_bytes = 0;
     double* oscr = nullptr; // observation models: f, d/df and per-lattice sums when the caller does not keep them
     size_t oscr_bytes = 0;
-    cplx* ltmp = nullptr; // scratch lines of the long-row passes (gpt_long.hip)
-    size_t ltmp_bytes = 0;
     char* arena = nullptr; // device staging arena of the host-pointer entry points
     size_t arena_bytes = 0;
     double* pinned = nullptr; // small pinned scratch for scalar read-backs
@@ -620,7 +618,6 @@ int gpt_destroy(gpt_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->partials) (void)hipFree(c->partials);
     if (c->arena) (void)hipFree(c->arena);
-    if (c->ltmp) (void)hipFree(c->ltmp);
     if (c->kscr) (void)hipFree(c->kscr);
     if (c->oscr) (void)hipFree(c->oscr);
     if (c->sink) (void)hipFree(c->sink);
@@ -700,16 +697,10 @@ static int slab_check(gpt_ctx* c, int64_t H, int64_t W) {
         return fail(c, GPT_ERR_UNSUPPORTED, "slab passes need a power-of-two height and width in [256, 32768]");
     return GPT_OK;
 }
-// twiddles of the sub-lines and scratch of the long-row passes (no-ops for rows one workgroup holds)
-static int slab_long_rows(gpt_ctx* c, LatArgs& a, int64_t rows, cplx** tmp) {
-    *tmp = nullptr;
-    const int R = gpt_long_row_split_radix(a.W);
-    if (R <= 0) return GPT_OK;
-    int rc = get_twiddles(c, a.W / R, &a.tw_sub);
-    if (rc) return rc;
-    if ((rc = ensure(c, c->ltmp, c->ltmp_bytes, gpt_long_row_tmp_elems(rows, a.W) * sizeof(cplx))) != GPT_OK) return rc;
-    *tmp = c->ltmp;
-    return GPT_OK;
+// twiddles of the W / 2-point lines of long rows (a no-op for rows whose two-for-one line one workgroup holds)
+static int slab_long_rows(gpt_ctx* c, LatArgs& a) {
+    if (gpt_long_row_split_radix(a.W) <= 0) return GPT_OK;
+    return get_twiddles(c, a.W / 2, &a.tw_sub);
 }
 static int slab_cus(gpt_ctx* c) {
     if (c->total_cus == 0) {
@@ -747,10 +738,9 @@ static int slab_rows_fwd(gpt_ctx* c, const double* y, const double* loc, int64_t
     a.x = y;
     a.loc = loc;
     if ((rc = slab_blocking(c, a, rows, W, block_cols, &ld)) != GPT_OK) return rc;
-    cplx* tmp = nullptr;
-    if ((rc = slab_long_rows(c, a, rows, &tmp)) != GPT_OK) return rc;
+    if ((rc = slab_long_rows(c, a)) != GPT_OK) return rc;
     HIP_TRY(c, gpt_pow2_slab_pass(0, OP_LPDF_VJP, a, reinterpret_cast<cplx*>(spec), (int)ld, 1.0, nullptr,
-                                  slab_cus(c), tmp, nullptr, c->stream));
+                                  slab_cus(c), nullptr, c->stream));
     return GPT_OK;
 }
 int gpt_slab_rows_fwd(gpt_ctx* c, const double* y, const double* loc, int64_t rows, int64_t H, int64_t W,
@@ -800,7 +790,7 @@ static int slab_cols(gpt_ctx* c, double* spec, int64_t ld, const double* cov, do
     a.out_cov = out_cov - cov_col0;
     if (cov_ld != W / 2 + 1) a.cov_ld = (int)cov_ld;
     HIP_TRY(c, gpt_pow2_slab_pass(1, OP_LPDF_VJP, a, reinterpret_cast<cplx*>(spec), (int)ld, 1.0, c->partials, cus,
-                                  nullptr, edge, c->stream));
+                                  edge, c->stream));
     return GPT_OK;
 }
 int gpt_slab_cols_lpdf_vjp(gpt_ctx* c, double* spec, int64_t ld, const double* cov, double* out_cov, int64_t H,
@@ -829,10 +819,9 @@ static int slab_rows_inv(gpt_ctx* c, const double* spec, int64_t ld, int64_t blo
     if ((rc = make_plan(c, a.W, a.pw)) != GPT_OK) return rc;
     a.out = out;
     if ((rc = slab_blocking(c, a, rows, W, block_cols, &ld)) != GPT_OK) return rc;
-    cplx* tmp = nullptr;
-    if ((rc = slab_long_rows(c, a, rows, &tmp)) != GPT_OK) return rc;
+    if ((rc = slab_long_rows(c, a)) != GPT_OK) return rc;
     HIP_TRY(c, gpt_pow2_slab_pass(2, OP_LPDF_VJP, a, const_cast<cplx*>(reinterpret_cast<const cplx*>(spec)), (int)ld,
-                                  alpha, nullptr, slab_cus(c), tmp, nullptr, c->stream));
+                                  alpha, nullptr, slab_cus(c), nullptr, c->stream));
     return GPT_OK;
 }
 int gpt_slab_rows_inv(gpt_ctx* c, const double* spec, int64_t ld, int64_t rows, int64_t H, int64_t W, double alpha,

@@ -30,13 +30,12 @@ int gpt_pow2_col_tile(int H);
 bool gpt_slab_supported(int H, int W);
 int gpt_long_row_split_radix(int W);
 int gpt_long_col_split_radix(int H);
-size_t gpt_long_row_tmp_elems(int64_t rows, int W);
 int gpt_slab_col_tile(int H);
 int gpt_slab_col_blocks(int H, int ncols, int cus);
 // `edge` (pass 1, may be null): 4 H doubles -- cov[:, 0], cov[:, W/2] staged by the caller, then d/dcov of the same two
 // columns written by the pass (a rank that owns only its columns of cov keeps these two apart).
 hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, int ld, double alpha, double* partials,
-                              int cus, cplx* tmp, double* edge, hipStream_t st);
+                              int cus, double* edge, hipStream_t st);
 
 // Non-centred model density: inverse rows -> observation model -> forward rows in place on the workspace, between
 // pass 1 of OP_GP_INV_RFFT2 and pass 1 of OP_INV_VJP (rows of up to 8192 points). o.partials holds

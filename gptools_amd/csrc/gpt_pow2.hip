@@ -186,15 +186,6 @@ int gpt_pow2_col_tile(int H) {
 // route; GPT_LONG_MIN=<n> sends every line of at least n points (n >= 2048) that way (tests).
 hipError_t gpt_long_rowstep(bool inverse, int R, cplx* spec, int64_t ld, int HS, int ncols, const cplx* twH,
                             hipStream_t st);
-int gpt_long_row_radix();
-hipError_t gpt_long_row_fwd1(const double* y, const double* loc, int64_t rows, int W, cplx* tmp, const cplx* twW,
-                             hipStream_t st);
-hipError_t gpt_long_row_split(const cplx* tmp, int64_t rows, int W, cplx* spec, int64_t ld, int cshift, int blk,
-                              hipStream_t st);
-hipError_t gpt_long_row_merge(const cplx* spec, int64_t ld, int64_t rows, int W, cplx* tmp, int cshift, int blk,
-                              hipStream_t st);
-hipError_t gpt_long_row_inv3(const cplx* tmp, int64_t rows, int W, double alpha, double* out, const cplx* twW,
-                             hipStream_t st);
 static int long_min() {
     static const int v = [] {
         const char* e = getenv("GPT_LONG_MIN");
@@ -204,10 +195,11 @@ static int long_min() {
     return v;
 }
 static bool pow2_between(int n, int lo, int hi) { return n >= lo && n <= hi && (n & (n - 1)) == 0; }
-// radix of the four-step route for a row of W points (0: one workgroup holds the line)
+// Rows of W points: 0 = two real rows share one complex line of W points (one workgroup holds it), 2 = long rows, one
+// real row per complex line of W / 2 points (rowreal_*_kernel), -1 = unsupported
 int gpt_long_row_split_radix(int W) {
     if (!pow2_between(W, 256, 32768)) return -1;
-    return (W > 16384 || W >= long_min()) ? gpt_long_row_radix() : 0;
+    return (W > 16384 || W >= long_min()) ? 2 : 0;
 }
 // ... and for a column of H points: sub-lines of GPT_LONG_HS points (4096, or 2048: two workgroups per CU in the
 // sub-line column kernel but a radix-16 step; measured 47.1 ms against 42.5 ms per 32768^2 evaluation on one GPU)
@@ -223,10 +215,6 @@ int gpt_long_col_split_radix(int H) {
     return H / hs;
 }
 bool gpt_slab_supported(int H, int W) { return gpt_long_row_split_radix(W) >= 0 && gpt_long_col_split_radix(H) >= 0; }
-// complex scratch elements the long-row passes need for `rows` rows of width W (0: none)
-size_t gpt_long_row_tmp_elems(int64_t rows, int W) {
-    return gpt_long_row_split_radix(W) > 0 ? (size_t)(rows / 2) * (size_t)W : 0;
-}
 int gpt_slab_col_tile(int H) {
     const int R = gpt_long_col_split_radix(H);
     if (R <= 0) return gpt_pow2_col_tile(H);
@@ -253,30 +241,18 @@ int gpt_slab_col_blocks(int H, int ncols, int cus) {
 //   pass 1: column pass of `op` on packed columns a.col0 .. a.col0 + a.ncols - 1, all a.H rows; spec[H][ld];
 //           the per-workgroup partials are summed into a.out_lpdf[0] (no constant added) and a.min_eig[0]
 //   pass 2: spec[rows][ld] -> a.out[rows][W] = alpha * (inverse row transform)
-// Long lines: `tmp` = scratch of gpt_long_row_tmp_elems complex (passes 0, 2), a.tw_sub = twiddles of the
-// sub-line length (W / 8 for the row passes, H / R for the column pass).
+// Long lines: a.tw_sub = twiddles of the line the kernels transform (W / 2 for the row passes of long rows, H / R for
+// the column pass of long columns).
 hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, int ld, double alpha, double* partials,
-                              int cus, cplx* tmp, double* edge, hipStream_t st) {
+                              int cus, double* edge, hipStream_t st) {
     const int edge_flags = edge ? 3 : 0; // pass 1: cov of the two self-mirrored columns staged by the caller, their d/dcov returned
     if (pass == 0 || pass == 2) {
         const int RWd = gpt_long_row_split_radix(a.W);
         if (RWd < 0) return hipErrorInvalidValue;
-        if (RWd > 0) {
-            if (!tmp || !a.tw_sub) return hipErrorInvalidValue;
-            const int64_t rows = a.H, nlines = (rows / 2) * RWd;
-            hipError_t e;
-            if (pass == 0) {
-                e = gpt_long_row_fwd1(a.x, a.loc, rows, a.W, tmp, a.pw.tw, st);
-                if (e != hipSuccess) return e;
-                e = sub_by_size(a.W / RWd, [&](auto l) { return decltype(l)::line_fft(false, tmp, nlines, a.tw_sub, st); });
-                if (e != hipSuccess) return e;
-                return gpt_long_row_split(tmp, rows, a.W, spec, ld, a.spec_cshift, a.spec_blk, st);
-            }
-            e = gpt_long_row_merge(spec, ld, rows, a.W, tmp, a.spec_cshift, a.spec_blk, st);
-            if (e != hipSuccess) return e;
-            e = sub_by_size(a.W / RWd, [&](auto l) { return decltype(l)::line_fft(true, tmp, nlines, a.tw_sub, st); });
-            if (e != hipSuccess) return e;
-            return gpt_long_row_inv3(tmp, rows, a.W, alpha, a.out, a.pw.tw, st);
+        if (RWd > 0) { // one real row per complex line of W / 2 points: one sweep each way
+            if (!a.tw_sub) return hipErrorInvalidValue;
+            if (pass == 0) return by_size(a.W / 2, [&](auto l) { return decltype(l)::rowreal_fwd(a, spec, ld, a.tw_sub, st); });
+            return by_size(a.W / 2, [&](auto l) { return decltype(l)::rowreal_inv(a, alpha, spec, ld, a.tw_sub, st); });
         }
     }
     if (pass == 0)

@@ -448,6 +448,8 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
             if (q == W / 2) v[m] = make_double2(A.y, B.y); // Nyquist terms ride in the imaginary slot of column 0
             else v[m] = make_double2(A.x + B.y, -A.y + B.x); // conj(A) + i conj(B)
         }
+        if (Geo<W>::ROW_THREADS >= 1024) // (128 registers: keep the merge from sinking into the transform, see rowreal_inv_kernel)
+            asm volatile("" : "+v"(v[m].x), "+v"(v[m].y));
     }
     fft_regs<W, true>(v, t, lds, wpre);
     if (fin.partials && blockIdx.x == 0) {
@@ -483,6 +485,170 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
             __builtin_nontemporal_store(alpha * v[m].y, o1 + t + T * m);
         }
     }
+}
+
+// Long rows ------------------------------------------------------------------------------------------
+// Rows of W = 2 N points whose two-for-one complex line (W points) no workgroup can hold (W = 32768: BASELINE config 5,
+// the slab passes): ONE real row is one complex line of N = W / 2 points, z[n] = x[2n] + i x[2n+1] -- a contiguous
+// 16-byte load per lane -- and with Z = FFT_N(z), E[k] = (Z[k] + conj Z[N-k]) / 2, O[k] = (Z[k] - conj Z[N-k]) / (2i):
+//     X[k] = E[k] + w_W^k O[k],  k = 0 .. N      (X[0] = Re Z[0] + Im Z[0], X[N] = Re Z[0] - Im Z[0]: both real)
+// which goes to the packed spectrum row as it is (column 0 = X[0] + i X[N]). One workgroup per row, ONE sweep over
+// y / loc and the spectrum; round 2 took three (radix-8 step into scratch lines, eight sub-line transforms, split).
+// a.H = rows of this call, a.W = W, a.pw.tw = w_W^m, twN = w_N^m.
+// Geometry: lines of 16384 points run 512 threads with two register tiles each (256 registers: the 1024-thread,
+// one-tile form has 128 and spilled 74 of them in the inverse kernel); shorter lines one tile per thread.
+template <int N> struct GeoR {
+    static constexpr int T = N / E;
+    static constexpr int V = N >= 16384 ? 2 : 1;
+    static constexpr int TP = T / V;                  // threads per line
+    static constexpr int THREADS = TP < 256 ? 256 : TP;
+    static constexpr int LINES = THREADS / TP;
+};
+template <int N>
+__global__ void __launch_bounds__(GeoR<N>::THREADS) rowreal_fwd_kernel(LatArgs a, cplx* __restrict__ spec, int ld,
+                                                                       const cplx* __restrict__ twN) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = GeoR<N>::T, V = GeoR<N>::V, TP = GeoR<N>::TP, LINES = GeoR<N>::LINES, W = 2 * N;
+    constexpr int NPRE = tw_npre<N>();
+    const int line = threadIdx.x / TP, tp = threadIdx.x - line * TP;
+    double* lds = reinterpret_cast<double*>(smem) + (size_t)line * N;
+    const int r = blockIdx.x * LINES + line;
+    const bool active = r < a.H;
+    int rr = active ? r : 0;
+    if (LINES == 1) rr = __builtin_amdgcn_readfirstlane(rr); // uniform row base: scalar base + 32-bit lane offsets
+    const double* x = a.x + (int64_t)rr * W;
+    int tl[V];
+    cplx wl[V][NPRE > 0 ? NPRE : 1];
+    cplx v[V][E];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        tl[k] = tp + k * TP;
+        tw_load<N>(wl[k], twN, tl[k]);
+#pragma unroll
+        for (int m = 0; m < E; ++m) { // read once: non-temporal
+            const gpt_rd2v u = __builtin_nontemporal_load(reinterpret_cast<const gpt_rd2v*>(x + 2u * (unsigned)(tl[k] + T * m)));
+            v[k][m] = make_double2(u.x, u.y);
+        }
+    }
+    if (a.loc) {
+        const double* l = a.loc + (int64_t)rr * W;
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const cplx u = *reinterpret_cast<const cplx*>(l + 2u * (unsigned)(tl[k] + T * m));
+                v[k][m].x -= u.x;
+                v[k][m].y -= u.y;
+            }
+    }
+    fft_regs<N, false, V, 0>(v, tl, lds, wl);
+    // A thread finishes the frequencies j = tl + T m, m < E/2, AND their mirrors N - j: both need exactly Z[j] (own
+    // register) and Z[N - j] (through LDS, re then im), X[N - j] = conj(E[j] - w^j O[j]).
+    cplx zc[V][E / 2];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+#pragma unroll
+        for (int m = 0; m < E; ++m) lds[phys(tl[k] + T * m)] = v[k][m].x;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+#pragma unroll
+        for (int m = 0; m < E / 2; ++m) zc[k][m].x = lds[phys((N - (tl[k] + T * m)) & (N - 1))];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+#pragma unroll
+        for (int m = 0; m < E; ++m) lds[phys(tl[k] + T * m)] = v[k][m].y;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+#pragma unroll
+        for (int m = 0; m < E / 2; ++m) zc[k][m].y = lds[phys((N - (tl[k] + T * m)) & (N - 1))];
+    if (!active) return;
+    cplx* s = spec + (int64_t)rr * ld;
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+#pragma unroll
+        for (int m = 0; m < E / 2; ++m) {
+            const int j = tl[k] + T * m;
+            const cplx z = v[k][m];
+            if (j == 0) {
+                s[spec_col(a, 0)] = make_double2(z.x + z.y, z.x - z.y); // DC + i Nyquist
+                s[spec_col(a, N / 2)] = cconj(v[0][E / 2]);             // X[N/2] = conj Z[N/2] (position 0 holds it)
+            } else {
+                const cplx e = make_double2(0.5 * (z.x + zc[k][m].x), 0.5 * (z.y - zc[k][m].y));
+                const cplx wo = cmul(a.pw.tw[(unsigned)j], make_double2(0.5 * (z.y + zc[k][m].y), -0.5 * (z.x - zc[k][m].x)));
+                s[spec_col(a, j)] = cadd(e, wo);
+                s[spec_col(a, N - j)] = cconj(csub(e, wo));
+            }
+        }
+}
+
+// The way back: Z[k] = E[k] + i O[k] with E[k] = (X[k] + conj X[N-k]) / 2, O[k] = conj(w_W^k) (X[k] - conj X[N-k]) / 2,
+// unnormalised inverse transform of N points = N z; out = 2 alpha * (that), so that alpha keeps the meaning it has in
+// row_inv_kernel (a factor on the unnormalised inverse transform of W points).
+template <int N>
+__global__ void __launch_bounds__(GeoR<N>::THREADS) rowreal_inv_kernel(LatArgs a, double alpha,
+                                                                       const cplx* __restrict__ spec, int ld,
+                                                                       const cplx* __restrict__ twN) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = GeoR<N>::T, V = GeoR<N>::V, TP = GeoR<N>::TP, LINES = GeoR<N>::LINES, W = 2 * N;
+    constexpr int NPRE = tw_npre<N>();
+    const int line = threadIdx.x / TP, tp = threadIdx.x - line * TP;
+    double* lds = reinterpret_cast<double*>(smem) + (size_t)line * N;
+    const int r = blockIdx.x * LINES + line;
+    const bool active = r < a.H;
+    int rr = active ? r : 0;
+    if (LINES == 1) rr = __builtin_amdgcn_readfirstlane(rr); // uniform row base: scalar base + 32-bit lane offsets
+    const cplx* s = spec + (int64_t)rr * ld;
+    int tl[V];
+    cplx wl[V][NPRE > 0 ? NPRE : 1];
+    cplx v[V][E];
+    constexpr int CH = 4; // entries whose A, B and twiddle loads are in flight together
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        tl[k] = tp + k * TP;
+        tw_load<N>(wl[k], twN, tl[k]);
+#pragma unroll
+        for (int m0 = 0; m0 < E; m0 += CH) {
+            cplx A[CH], B[CH], w[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int j = tl[k] + T * (m0 + i);
+                A[i] = s[spec_col(a, j)];
+                B[i] = s[spec_col(a, (N - j) & (N - 1))]; // (the mirrored half of the same row: served by the caches)
+                w[i] = a.pw.tw[(unsigned)j];
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int j = tl[k] + T * (m0 + i);
+                if (j == 0) {
+                    v[k][m0 + i] = make_double2(0.5 * (A[i].x + A[i].y), 0.5 * (A[i].x - A[i].y));
+                } else {
+                    const cplx e = make_double2(0.5 * (A[i].x + B[i].x), 0.5 * (A[i].y - B[i].y));
+                    const cplx d = make_double2(0.5 * (A[i].x - B[i].x), 0.5 * (A[i].y + B[i].y));
+                    const cplx o = cmulc(d, w[i]);
+                    v[k][m0 + i] = make_double2(e.x - o.y, e.y + o.x);
+                }
+                // pin the value here: otherwise the arithmetic sinks down to the transform and the raw A, B and w of
+                // all 32 entries (12 registers each instead of 4) stay alive and spill
+                asm volatile("" : "+v"(v[k][m0 + i].x), "+v"(v[k][m0 + i].y));
+            }
+            SCHED_FENCE();
+        }
+    }
+    fft_regs<N, true, V, 0>(v, tl, lds, wl);
+    if (!active) return;
+    double* out = a.out + (int64_t)rr * W;
+    const double al = 2.0 * alpha;
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const gpt_rd2v u = {al * v[k][m].x, al * v[k][m].y};
+            __builtin_nontemporal_store(u, reinterpret_cast<gpt_rd2v*>(out + 2u * (unsigned)(tl[k] + T * m)));
+        }
 }
 
 // pass C of gp_inv_rfft2, an observation model on the field, and pass A of the transform's reverse mode in one
@@ -840,6 +1006,10 @@ template <int N> struct Launch {
     static hipError_t row_obs(const LatArgs& a, double alpha, cplx* ws, int wstride, const FinArgs& fin, double* edge,
                               const ObsRowArgs& o, bool sub2, hipStream_t st);
     static int row_obs_blocks(int H) { return (H / 2 + Geo<N>::ROW_LINES - 1) / Geo<N>::ROW_LINES; }
+    // rows of 2 N points, one real row per complex line of N points (a.H rows of a.W = 2 N points; twN = w_N^m)
+    static hipError_t rowreal_fwd(const LatArgs& a, cplx* spec, int ld, const cplx* twN, hipStream_t st);
+    static hipError_t rowreal_inv(const LatArgs& a, double alpha, const cplx* spec, int ld, const cplx* twN,
+                                  hipStream_t st);
     // grid of the persistent column kernel = number of per-lattice partials, one workgroup per CU it may use
     static int col_tile() { return Geo<N>::TC; }
     static int col_blocks(int W, int cus) {

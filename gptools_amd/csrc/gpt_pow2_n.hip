@@ -64,6 +64,30 @@ hipError_t Launch<GPT_N>::row_inv(const LatArgs& a, double alpha, int add_loc, c
     return hipGetLastError();
 }
 
+template <>
+hipError_t Launch<GPT_N>::rowreal_fwd(const LatArgs& a, cplx* spec, int ld, const cplx* twN, hipStream_t st) {
+    constexpr int N = GPT_N;
+    if (a.W != 2 * N || a.batch != 1 || !twN) return hipErrorInvalidValue;
+    const size_t lds = (size_t)GeoR<N>::LINES * N * sizeof(double);
+    hipError_t e = raise_lds(rowreal_fwd_kernel<N>, lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)((a.H + GeoR<N>::LINES - 1) / GeoR<N>::LINES));
+    hipLaunchKernelGGL((rowreal_fwd_kernel<N>), grid, dim3(GeoR<N>::THREADS), lds, st, a, spec, ld, twN);
+    return hipGetLastError();
+}
+template <>
+hipError_t Launch<GPT_N>::rowreal_inv(const LatArgs& a, double alpha, const cplx* spec, int ld, const cplx* twN,
+                                      hipStream_t st) {
+    constexpr int N = GPT_N;
+    if (a.W != 2 * N || a.batch != 1 || !twN) return hipErrorInvalidValue;
+    const size_t lds = (size_t)GeoR<N>::LINES * N * sizeof(double);
+    hipError_t e = raise_lds(rowreal_inv_kernel<N>, lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)((a.H + GeoR<N>::LINES - 1) / GeoR<N>::LINES));
+    hipLaunchKernelGGL((rowreal_inv_kernel<N>), grid, dim3(GeoR<N>::THREADS), lds, st, a, alpha, spec, ld, twN);
+    return hipGetLastError();
+}
+
 #if GPT_N <= 8192
 template <>
 hipError_t Launch<GPT_N>::row_obs(const LatArgs& a, double alpha, cplx* ws, int wstride, const FinArgs& fin, double* edge,

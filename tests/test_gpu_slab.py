@@ -335,3 +335,22 @@ def test_bench_slab_spectrum_columns_match_the_kernel():
     for col0, nc in ((0, 128), (384, 128), (w // 2, 1)):
         got = bench.matern_cov_columns(1.5, h, w, 1.3, (8.0, 12.0), col0, nc, dev)
         torch.testing.assert_close(got, full[:, col0:col0 + nc], rtol=1e-12, atol=0.0)
+
+
+@pytest.mark.skipif(not os.environ.get("GPT_LONG_MIN"), reason="run by test_slab_long_route_at_small_sizes in a child process")
+@pytest.mark.parametrize("h,w,world", [(2048, 2048, 1), (2048, 4096, 2), (4096, 2048, 4), (256, 8192, 2), (8192, 16384, 1)])
+def test_slab_forced_long_route(h, w, world):
+    test_slab_matches_oracle(h, w, world)
+
+
+def test_slab_long_route_at_small_sizes():
+    """GPT_LONG_MIN=2048 sends every line of at least 2048 points down the long-line route (rows: one real row per
+    complex line of W / 2 points, rowreal_*_kernel at N = 1024 ... 8192, both thread geometries; columns: radix-8 step +
+    sub-line kernels), so that every instantiation of those kernels meets the oracle, not only the 32768-point ones."""
+    import subprocess
+
+    env = dict(os.environ, GPT_LONG_MIN="2048")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                          "test_slab_forced_long_route", "-p", "no:cacheprovider"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert out.returncode == 0 and "5 passed" in out.stdout, out.stdout[-3000:]
