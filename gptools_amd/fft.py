@@ -22,6 +22,7 @@ import torch
 from . import _lib
 
 _tls = threading.local()  # .contexts: device index -> Context, one set per thread, freed when the thread ends
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # (device index) -> the current stream's handle
 
 
 class NotPositiveDefinite(ValueError):
@@ -43,6 +44,7 @@ class Context:
         if rc != 0:
             raise RuntimeError(f"gpt_create failed with status {rc}")
         self.handle = h
+        self._fns = {}
         # the context owns device memory (workspace, twiddles, staging): give it back when the Context object goes
         # (its thread ended, or close() was called)
         self._finalizer = weakref.finalize(self, self.lib.gpt_destroy, h)
@@ -54,7 +56,8 @@ class Context:
         self.handle = None
 
     def sync_stream(self):
-        cur = torch.cuda.current_stream(self.device).cuda_stream  # (no device-guard round trip: this runs on every call)
+        # this runs on every call: the raw stream handle, without building a torch.cuda.Stream object around it
+        cur = _raw_stream(self.device) if _raw_stream else torch.cuda.current_stream(self.device).cuda_stream
         if cur != self.stream:
             rc = self.lib.gpt_set_stream(self.handle, ctypes.c_void_p(cur))
             if rc != 0:
@@ -66,7 +69,12 @@ class Context:
 
     def call(self, name, *args):
         self.sync_stream()
-        rc = getattr(self.lib, name)(self.handle, *args)
+        fn = self._fns.get(name)
+        if fn is None:
+            fn = self._fns[name] = getattr(self.lib, name)
+        rc = fn(self.handle, *args)
+        if rc == 0:
+            return
         if rc == _lib.GPT_ERR_SHAPE:
             raise ValueError(self.error())
         if rc == _lib.GPT_ERR_UNSUPPORTED:
@@ -76,16 +84,20 @@ class Context:
 
 
 def get_context(device=None) -> Context:
+    if isinstance(device, torch.device):
+        device = device.index
     if device is None:
         device = torch.cuda.current_device()
-    if isinstance(device, torch.device):
-        device = device.index if device.index is not None else torch.cuda.current_device()
+    try:
+        ctx = _tls.contexts[device]  # the common case: one dictionary look-up per call
+        if ctx.handle is not None:
+            return ctx
+    except (AttributeError, KeyError):
+        pass
     table = getattr(_tls, "contexts", None)
     if table is None:
         table = _tls.contexts = {}
-    ctx = table.get(device)
-    if ctx is None or ctx.handle is None:
-        ctx = table[device] = Context(device)
+    ctx = table[device] = Context(device)
     return ctx
 
 
@@ -109,6 +121,8 @@ def _p(t):
 
 
 def _dev(x, like=None):
+    if isinstance(x, torch.Tensor) and x.is_cuda and x.dtype is torch.float64:
+        return x  # (the sampler's case: nothing to convert)
     if not isinstance(x, torch.Tensor):
         # through numpy: torch.as_tensor would round Python floats to float32
         a = np.asarray(x)
@@ -154,7 +168,9 @@ def _prep(main, loc, cov, dim1):
     core = 1 if dim1 else 2
     # batch dimensions broadcast like the reference's NumPy mirror (fft2.py: `(..., H, W)` arrays): loc / cov with MORE
     # batch dimensions than the lattice argument expand it
-    others = [torch.Size(t.shape[:-core]) for t in (loc, cov) if hasattr(t, "shape") and len(t.shape) > core]
+    mb = main.shape[:-core]
+    others = [torch.Size(t.shape[:-core]) for t in (loc, cov)
+              if hasattr(t, "shape") and len(t.shape) > core and t.shape[:-core] != mb]
     if others:
         full = torch.broadcast_shapes(torch.Size(main.shape[:-core]), *others)
         if tuple(full) != tuple(main.shape[:-core]):

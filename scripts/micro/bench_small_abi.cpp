@@ -1,0 +1,105 @@
+// BASELINE configs 1-3 at the C ABI, where a sampler calls (no Python in the loop): microseconds per call of the fused
+// value + gradient entry point
+//   dev     gpt_gp_rfft2_lpdf_vjp, device pointers, `iters` back-to-back calls, one synchronisation at the end
+//   graph   gpt_gp_rfft2_lpdf_vjp_noalloc captured into a HIP graph once, `iters` replays (the entry point that makes
+//           no allocation is the one a capture can hold)
+//   host    gpt_gp_rfft2_lpdf_host, host pointers, column-major (what the Stan header calls; synchronous)
+// One JSON object per line.
+//   build: hipcc -O2 -std=c++17 -I include scripts/micro/bench_small_abi.cpp -o scripts/micro/bench_small_abi \
+//          -L gptools_amd -lgptools_hip -Wl,-rpath,'$ORIGIN/../../gptools_amd'
+#include "gptools_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+#define GK(x) do { int r_ = (x); if (r_ != GPT_OK) { printf("%s -> %d: %s\n", #x, r_, gpt_last_error(ctx)); exit(1); } } while (0)
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main() {
+    struct Case { const char* label; int64_t H, W, batch; };
+    const Case cases[] = {{"config 1: 1-D n=128, one chain", 1, 128, 1},        {"config 1 (docs): 1-D n=100, one chain", 1, 100, 1},
+                          {"config 2: 35x60, 1 chain per launch", 35, 60, 1},   {"config 2: 35x60, 64 chains per launch", 35, 60, 64},
+                          {"config 2: 35x60, 4096 chains per launch", 35, 60, 4096},
+                          {"config 3: 1-D n=128, 64 chains per launch", 1, 128, 64}, {"config 3: 1-D n=144, 64 chains per launch", 1, 144, 64},
+                          {"config 3: 1-D n=160, 64 chains per launch", 1, 160, 64}, {"config 3: 1-D n=176, 64 chains per launch", 1, 176, 64},
+                          {"config 3: 1-D n=192, 64 chains per launch", 1, 192, 64}};
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    gpt_ctx* ctx = nullptr;
+    if (gpt_create(0, st, &ctx) != GPT_OK) return 1;
+    std::mt19937_64 g(1);
+    std::normal_distribution<double> nd;
+    const int iters = 2000;
+    for (const Case& c : cases) {
+        const int dim1 = c.H == 1;
+        const size_t hw = (size_t)(c.H * c.W), hwf = (size_t)(c.H * (c.W / 2 + 1)), B = (size_t)c.batch;
+        std::vector<double> y(B * hw), loc(hw), cov(B * hwf), lp(B), gy(B * hw), gc(B * hwf);
+        for (auto& v : y) v = nd(g);
+        for (auto& v : loc) v = nd(g);
+        for (auto& v : cov) v = 1.0 + 0.5 * std::fabs(nd(g)); // every chain its own spectrum
+        double *dy, *dl, *dc, *dlp, *dgy, *dgc, *dmn;
+        CK(hipMalloc(&dy, B * hw * 8)); CK(hipMalloc(&dl, hw * 8)); CK(hipMalloc(&dc, B * hwf * 8));
+        CK(hipMalloc(&dlp, B * 8)); CK(hipMalloc(&dgy, B * hw * 8)); CK(hipMalloc(&dgc, B * hwf * 8)); CK(hipMalloc(&dmn, B * 8));
+        CK(hipMemcpy(dy, y.data(), B * hw * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dl, loc.data(), hw * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dc, cov.data(), B * hwf * 8, hipMemcpyHostToDevice));
+        auto dev_call = [&] {
+            GK(gpt_gp_rfft2_lpdf_vjp(ctx, dy, (int64_t)hw, dl, 0, dc, (int64_t)hwf, c.H, c.W, c.batch, dim1, dlp, dgy, dgc, dmn));
+        };
+        for (int i = 0; i < 20; ++i) dev_call();
+        CK(hipStreamSynchronize(st));
+        double t0 = now();
+        for (int i = 0; i < iters; ++i) dev_call();
+        CK(hipStreamSynchronize(st));
+        const double us_dev = 1e6 * (now() - t0) / iters;
+        // the allocation-free entry point under stream capture
+        double us_graph = -1.0;
+        {
+            hipGraph_t graph;
+            hipGraphExec_t exec;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+            const int rc = gpt_gp_rfft2_lpdf_vjp_noalloc(ctx, dy, (int64_t)hw, dl, 0, dc, (int64_t)hwf, c.H, c.W, c.batch, dim1, dlp, dgy, dgc, dmn);
+            CK(hipStreamEndCapture(st, &graph));
+            if (rc == GPT_OK) {
+                CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                for (int i = 0; i < 20; ++i) CK(hipGraphLaunch(exec, st));
+                CK(hipStreamSynchronize(st));
+                t0 = now();
+                for (int i = 0; i < iters; ++i) CK(hipGraphLaunch(exec, st));
+                CK(hipStreamSynchronize(st));
+                us_graph = 1e6 * (now() - t0) / iters;
+                CK(hipGraphExecDestroy(exec));
+            }
+            CK(hipGraphDestroy(graph));
+        }
+        // the Stan-side call: one chain, host pointers, column-major, synchronous
+        double us_host = -1.0;
+        if (c.batch == 1) {
+            double mn = 0.0;
+            auto host_call = [&] {
+                const int rc = gpt_gp_rfft2_lpdf_host(ctx, GPT_COL_MAJOR, y.data(), loc.data(), cov.data(), c.H, c.W, dim1, lp.data(), gy.data(), gc.data());
+                if (rc != GPT_OK) { printf("host call -> %d: %s\n", rc, gpt_last_error(ctx)); exit(1); }
+            };
+            (void)mn;
+            for (int i = 0; i < 20; ++i) host_call();
+            t0 = now();
+            for (int i = 0; i < 500; ++i) host_call();
+            us_host = 1e6 * (now() - t0) / 500;
+        }
+        printf("{\"case\": \"%s\", \"us_per_call_device_ptr\": %.2f, \"evals_per_s_device_ptr\": %.0f, \"us_per_graph_replay_noalloc\": %.2f, "
+               "\"us_per_call_host_ptr_col_major\": %.2f}\n",
+               c.label, us_dev, c.batch / (1e-6 * us_dev), us_graph, us_host);
+        fflush(stdout);
+        CK(hipFree(dy)); CK(hipFree(dl)); CK(hipFree(dc)); CK(hipFree(dlp)); CK(hipFree(dgy)); CK(hipFree(dgc)); CK(hipFree(dmn));
+    }
+    gpt_destroy(ctx);
+    return 0;
+}
