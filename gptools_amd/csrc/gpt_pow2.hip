@@ -28,30 +28,23 @@ template <typename F> hipError_t sub_by_size(int n, F f) {
     }
 }
 #ifndef GPT_SUB_DEFAULT
-#define GPT_SUB_DEFAULT 4
+#define GPT_SUB_DEFAULT 2
 #endif
-// Radix of the step across rows: GPT_SUBLINE=0 keeps the whole-column kernels, 2 the radix-2 split everywhere (A/B
-// timing; all are parity-tested), anything else / unset: the rule of gpt_pow2_sub_radix.
+// Radix of the step across rows: GPT_SUBLINE=0 keeps the whole-column kernels (A/B timing; both are parity-tested).
 int sub_choice() {
     static const int r = [] {
         const char* e = getenv("GPT_SUBLINE");
         if (!e) return GPT_SUB_DEFAULT;
-        return e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 4);
+        return e[0] == '0' ? 0 : 2;
     }();
     return r;
 }
 } // namespace
 
-// Sub-line variant (gpt_pow2_sub.h): whole lattices whose columns split into R sub-lines of 256..4096 points.
-// R = 4 for the log-density ops on lattices of 4096 rows (8-column x 1024-row tiles, two workgroups per CU: pass B
-// 103 -> 85 us per 4096 x 4096 lattice) where the row kernels have the radix-4 form (rows of 2048..8192 points);
-// the kernel-fused ops keep R = 2 (their column pass is bound by arithmetic, not by its tiles: 79 us either way, and
-// their row passes are cheaper), and so does every other op and height.
+// Sub-line variant (gpt_pow2_sub.h): whole lattices whose columns split into two sub-lines of 256..4096 points.
 int gpt_pow2_sub_radix(int op, int H, int W) {
     const int r = sub_choice();
     if (r == 0 || op < 0 || op >= OP_COUNT || !gpt_pow2_supported(H, W)) return 0;
-    if (r == 4 && H == 4096 && W >= 2048 && W <= 8192 && (op == OP_LPDF || op == OP_LPDF_VJP || op == OP_LPDF_VJP_NOCOV))
-        return 4;
     return (H >= 512 && H <= 8192) ? 2 : 0; // sub-lines of 256..4096 points, any row length, every op
 }
 static int sub_col_blocks(int R, int H, int W, int cus) {
@@ -85,11 +78,10 @@ static int whole_col_blocks(int H, int W, int cus) {
 // upper bound over the kernels a lattice of this shape may run (sizes the partials buffer)
 int gpt_pow2_col_blocks(int H, int W, int cus) {
     int nb = whole_col_blocks(H, W, cus);
-    for (int op : {OP_LPDF_VJP, OP_LPDF_KVJP, OP_GP_RFFT2}) // (one op of every sub-line radix / geometry in use)
-        if (const int R = gpt_pow2_sub_radix(op, H, W)) {
-            const int ns = sub_col_blocks(R, H, W, cus);
-            if (ns > nb) nb = ns;
-        }
+    if (const int R = gpt_pow2_sub_radix(OP_LPDF_VJP, H, W)) { // (the widest grid of the variants)
+        const int ns = sub_col_blocks(R, H, W, cus);
+        if (ns > nb) nb = ns;
+    }
     return nb;
 }
 
@@ -112,7 +104,7 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
     if (pass == 0) {
         if (!op_has_fwd(op)) return hipSuccess;
         const int in_mode = op == OP_RFFT2 ? 0 : (op == OP_INV_VJP ? 2 : 1);
-        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, in_mode, ws, wstride, (edge_flags & 1) ? edge : nullptr, R, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, in_mode, ws, wstride, (edge_flags & 1) ? edge : nullptr, R == 2, st); });
     }
     if (pass == 1) {
         hipError_t e;
@@ -149,7 +141,7 @@ hipError_t gpt_pow2_pass(int pass, int op, const LatArgs& a, cplx* ws, double* p
         if (op == OP_INV_RFFT2) alpha = 1.0 / n;
         else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
         else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
-        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, R, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, add_loc, ws, wstride, fin, (edge_flags & 2) ? edge : nullptr, R == 2, st); });
     }
     return hipErrorInvalidValue;
 }
@@ -264,7 +256,7 @@ hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, in
         }
     }
     if (pass == 0)
-        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, a.loc ? 1 : 0, spec, ld, nullptr, 0, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_fwd(a, a.loc ? 1 : 0, spec, ld, nullptr, false, st); });
     if (pass == 1) {
         const int R = gpt_long_col_split_radix(a.H);
         if (R < 0) return hipErrorInvalidValue;
@@ -286,7 +278,7 @@ hipError_t gpt_pow2_slab_pass(int pass, int op, const LatArgs& a, cplx* spec, in
     }
     if (pass == 2) {
         const FinArgs fin = {nullptr, 0, 0.0, nullptr, nullptr, nullptr, nullptr};
-        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, 0, spec, ld, fin, nullptr, 0, st); });
+        return by_size(a.W, [&](auto l) { return decltype(l)::row_inv(a, alpha, 0, spec, ld, fin, nullptr, false, st); });
     }
     return hipErrorInvalidValue;
 }

@@ -487,229 +487,6 @@ __global__ void __launch_bounds__(Geo<W>::ROW_THREADS) row_inv_kernel(LatArgs a,
     }
 }
 
-// Radix-4 sub-lines (gpt_pow2_sub.h with R = 4) ---------------------------------------------------------
-// The column transform of length H = 4 HS is split into one radix-4 step across rows HS apart and four sub-line
-// transforms of HS points, so that a pass-B tile of 8 columns x HS rows is 128 KB at H = 4096 and TWO workgroups share
-// a CU with whole 128-byte lines of the workspace and 64-byte pieces of cov / d/dcov (the radix-2 split leaves a choice
-// between wide tiles, one workgroup per CU, and overlap with 32-byte pieces). Timed before it was written
-// (GPT_SUB_TIMING_R4, profiles/r03_g_r4_timing.jsonl): pass B 103 -> 85 us per 4096 x 4096 lattice.
-// A workgroup takes the four rows r + HS p, p = 0..3, as two complex lines (one register tile per thread, as in
-// row_fwd_kernel): line 0 = rows (r, r + 2 HS), line 1 = rows (r + HS, r + 3 HS). After the transforms and the
-// two-for-one split line 0 holds S0, S2 and line 1 holds S1, S3 (S_p = spectrum of row r + HS p); with
-//     a = S0 + S2, b = S0 - S2   (line 0)        c = S1 + S3, d = S1 - S3   (line 1)
-// the radix-4 step (decimation in frequency) is
-//     u0 = a + c,  u2 = (a - c) w^2r   (line 0: needs c)        u1 = (b - i d) w^r,  u3 = (b + i d) w^3r   (line 1: needs b)
-// so each thread hands ONE complex value per frequency to its partner in the other line, through the LDS the
-// transforms are done with (8 values per thread, 64 KB per workgroup). u_q goes to workspace row q HS + r.
-template <int W, bool NTS>
-__global__ void __launch_bounds__(2 * Geo<W>::T, 4) row_fwd4_kernel(LatArgs a, int in_mode, cplx* __restrict__ ws,
-                                                                 int wstride, double* __restrict__ edge) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int T = Geo<W>::T;
-    static_assert(2 * T >= 256 && 2 * T <= 1024, "one row quad per workgroup");
-    const int line = threadIdx.x / T, t = threadIdx.x - line * T; // (line is uniform per wave: T is a multiple of 64)
-    double* lds = reinterpret_cast<double*>(smem) + (size_t)line * W;
-    // the hand-over area: W / 2 complex values per line = the line's own W doubles
-    cplx* mine = reinterpret_cast<cplx*>(smem) + (size_t)line * (W / 2);
-    const cplx* theirs = reinterpret_cast<const cplx*>(smem) + (size_t)(line ^ 1) * (W / 2);
-    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x; // lattice-fastest numbering, as row_fwd_kernel
-    const int64_t b = lin % gridDim.y;
-    const int H = a.H, HS = H / 4;
-    const int r = (int)(lin / gridDim.y); // row quad, < HS (the launcher's grid is exact)
-    const double* src = in_mode == 2 ? a.aux + b * a.aux_bs : a.x + b * a.x_bs;
-    const int ra = r + line * HS, rb = ra + 2 * HS; // the two rows of this line
-    const double* r0 = src + (int64_t)ra * W;
-    const double* r1 = src + (int64_t)rb * W;
-    cplx wpre[tw_npre<W>()];
-    tw_load<W>(wpre, a.pw.tw, t);
-    cplx v[E];
-#pragma unroll
-    for (int m = 0; m < E; ++m)
-        v[m] = make_double2(__builtin_nontemporal_load(r0 + t + T * m), __builtin_nontemporal_load(r1 + t + T * m));
-    if (in_mode == 1 && a.loc) {
-        const double* l0 = a.loc + b * a.loc_bs + (int64_t)ra * W;
-        const double* l1 = a.loc + b * a.loc_bs + (int64_t)rb * W;
-#pragma unroll
-        for (int m = 0; m < E; ++m) {
-            v[m].x -= l0[t + T * m];
-            v[m].y -= l1[t + T * m];
-        }
-    }
-    fft_regs<W, false>(v, t, lds, wpre);
-    cplx zc[E / 2]; // Z[W - j] through LDS, re then im (as row_fwd_kernel)
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m].x;
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < E / 2; ++m) {
-        const int j = t + T * m;
-        zc[m].x = lds[phys(j == 0 ? 0 : W - j)];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < E; ++m) lds[phys(t + T * m)] = v[m].y;
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < E / 2; ++m) {
-        const int j = t + T * m;
-        zc[m].y = lds[phys(j == 0 ? 0 : W - j)];
-    }
-    if (edge && a.cov && t == 0) { // the two edge columns of cov, staged contiguously for the column pass
-        const double* cv = a.cov + b * a.cov_bs;
-        const int wf = W / 2 + 1;
-        double* e = edge + b * 4 * (int64_t)H;
-        e[ra] = cv[(int64_t)ra * wf];
-        e[rb] = cv[(int64_t)rb * wf];
-        e[H + ra] = cv[(int64_t)ra * wf + W / 2];
-        e[H + rb] = cv[(int64_t)rb * wf + W / 2];
-    }
-    // sum and difference of this line's two row spectra: one is kept, the partner line gets the other (line 0 keeps
-    // a = S0 + S2 and gives b = S0 - S2; line 1 keeps d = S1 - S3 and gives c = S1 + S3) -- sg = +1 / -1 per line, so
-    // that only the kept value stays in registers across the hand-over
-    const double sg = line == 0 ? 1.0 : -1.0;
-    cplx keep[E / 2];
-    __syncthreads(); // the split is done with LDS
-#pragma unroll
-    for (int m = 0; m < E / 2; ++m) {
-        const int j = t + T * m;
-        const cplx z = v[m];
-        cplx za, zb;
-        if (j == 0) {
-            const cplx zn = v[E / 2]; // Z[W/2] lives in the same thread (t == 0, m == E/2)
-            za = make_double2(z.x, zn.x);
-            zb = make_double2(z.y, zn.y);
-        } else {
-            za = make_double2(0.5 * (z.x + zc[m].x), 0.5 * (z.y - zc[m].y));
-            zb = make_double2(0.5 * (z.y + zc[m].y), -0.5 * (z.x - zc[m].x));
-        }
-        keep[m] = make_double2(fma(sg, zb.x, za.x), fma(sg, zb.y, za.y));
-        mine[j] = make_double2(fma(-sg, zb.x, za.x), fma(-sg, zb.y, za.y));
-    }
-    __syncthreads();
-    cplx* s0 = ws + ((int64_t)b * H + (line == 0 ? r : HS + r)) * wstride;          // u0 | u1
-    cplx* s1 = ws + ((int64_t)b * H + (line == 0 ? 2 * HS + r : 3 * HS + r)) * wstride; // u2 | u3
-    // uniform twiddles w_H^(r q): line 0 needs q = 2, line 1 q = 1 and 3 (3 r < H)
-    const cplx w1 = a.ph.tw[line == 0 ? 2 * r : r], w3 = a.ph.tw[3 * r];
-#pragma unroll
-    for (int m = 0; m < E / 2; ++m) {
-        const int j = t + T * m;
-        const cplx o = theirs[j];
-        const unsigned jo = spec_col(a, j);
-        if (line == 0) {
-            rows_st<NTS>(&s0[jo], cadd(keep[m], o));            // u0 = a + c
-            rows_st<NTS>(&s1[jo], cmul(csub(keep[m], o), w1)); // u2 = (a - c) w^2r
-        } else {
-            const cplx id = make_double2(-keep[m].y, keep[m].x); // i d
-            rows_st<NTS>(&s0[jo], cmul(csub(o, id), w1));       // u1 = (b - i d) w^r
-            rows_st<NTS>(&s1[jo], cmul(cadd(o, id), w3));       // u3 = (b + i d) w^3r
-        }
-    }
-}
-
-// The mirror image (decimation in time, unnormalised): v'_q = conj(w^rq) v_q (workspace rows q HS + r),
-//     a' = v'0 + v'2, b' = v'0 - v'2   (line 0)        c' = v'1 + v'3, d' = v'1 - v'3   (line 1)
-//     S0 = a' + c', S2 = a' - c'   (line 0: needs c')   S1 = b' + i d', S3 = b' - i d'   (line 1: needs b')
-// A thread merges 16 frequency pairs (j and W - j) into its complex line, so it hands over 16 values: two rounds of 8
-// through the same LDS, then the inverse transform of row_inv_kernel.
-template <int W>
-__global__ void __launch_bounds__(2 * Geo<W>::T, 4) row_inv4_kernel(LatArgs a, double alpha, int add_loc,
-                                                                 const cplx* __restrict__ ws, int wstride, FinArgs fin,
-                                                                 const double* __restrict__ edge) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int T = Geo<W>::T;
-    const int line = threadIdx.x / T, t = threadIdx.x - line * T;
-    double* lds = reinterpret_cast<double*>(smem) + (size_t)line * W;
-    cplx* mine = reinterpret_cast<cplx*>(smem) + (size_t)line * (W / 2);
-    const cplx* theirs = reinterpret_cast<const cplx*>(smem) + (size_t)(line ^ 1) * (W / 2);
-    const int64_t b = blockIdx.y;
-    const int H = a.H, HS = H / 4;
-    const int r = blockIdx.x; // row quad
-    const int ra = r + line * HS, rb = ra + 2 * HS;
-    const cplx* s0 = ws + ((int64_t)b * H + (line == 0 ? r : HS + r)) * wstride;          // v0 | v1
-    const cplx* s1 = ws + ((int64_t)b * H + (line == 0 ? 2 * HS + r : 3 * HS + r)) * wstride; // v2 | v3
-    const cplx w0 = line == 0 ? make_double2(1.0, 0.0) : cconj(a.ph.tw[r]);
-    const cplx w1 = cconj(a.ph.tw[line == 0 ? 2 * r : 3 * r]);
-    const double sg = line == 0 ? 1.0 : -1.0;
-    cplx wpre[tw_npre<W>()];
-    tw_load<W>(wpre, a.pw.tw, t);
-    cplx v[E];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) { // frequencies j = t + T m (m < 8), then their mirrors W - j
-        cplx keep[E / 2]; // line 0 keeps a' and gives b', line 1 keeps d' and gives c'
-        __syncthreads();  // (the previous round's values have been read)
-#pragma unroll
-        for (int i = 0; i < E / 2; ++i) {
-            const int m = half * (E / 2) + i;
-            const int j = t + T * m;
-            const int q = W - j; // 1 .. W/2 when m >= E/2
-            const int col = m < E / 2 ? j : (q == W / 2 ? 0 : q);
-            const unsigned co = spec_col(a, col);
-            cplx A = s0[co];
-            if (line == 1) A = cmul(A, w0);
-            const cplx B = cmul(s1[co], w1);
-            keep[i] = make_double2(fma(sg, B.x, A.x), fma(sg, B.y, A.y));
-            mine[t + T * i] = make_double2(fma(-sg, B.x, A.x), fma(-sg, B.y, A.y));
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < E / 2; ++i) {
-            const int m = half * (E / 2) + i;
-            const int j = t + T * m;
-            const int q = W - j;
-            const cplx o = theirs[t + T * i];
-            cplx A, B; // spectra of this line's two rows (ra, rb) at this frequency
-            if (line == 0) {
-                A = cadd(keep[i], o); // S0 = a' + c'
-                B = csub(keep[i], o); // S2 = a' - c'
-            } else {
-                const cplx id = make_double2(-keep[i].y, keep[i].x); // i d'
-                A = cadd(o, id); // S1 = b' + i d'
-                B = csub(o, id); // S3 = b' - i d'
-            }
-            if (m < E / 2) {
-                if (j == 0) v[m] = make_double2(A.x, B.x); // DC terms are real
-                else v[m] = make_double2(A.x - B.y, A.y + B.x);
-            } else {
-                if (q == W / 2) v[m] = make_double2(A.y, B.y); // Nyquist terms ride in the imaginary slot of column 0
-                else v[m] = make_double2(A.x + B.y, -A.y + B.x); // conj(A) + i conj(B)
-            }
-            asm volatile("" : "+v"(v[m].x), "+v"(v[m].y)); // (keep the merge from sinking into the transform)
-        }
-    }
-    fft_regs<W, true>(v, t, lds, wpre); // (its first exchange starts with a barrier: the hand-over area is free by then)
-    if (fin.partials && blockIdx.x == 0) {
-        __syncthreads();
-        finalize_block(fin, b, reinterpret_cast<double*>(smem));
-    }
-    if (edge && a.out_cov && t == 0) { // d/dcov of the two edge columns, left contiguous by the column pass
-        const double* e = edge + b * 4 * (int64_t)H + 2 * (int64_t)H;
-        const int wf = W / 2 + 1;
-        double* oc = a.out_cov + b * (int64_t)H * wf;
-        oc[(int64_t)ra * wf] = e[ra];
-        oc[(int64_t)rb * wf] = e[rb];
-        oc[(int64_t)ra * wf + W / 2] = e[H + ra];
-        oc[(int64_t)rb * wf + W / 2] = e[H + rb];
-    }
-    double* o0 = a.out + b * (int64_t)H * W + (int64_t)ra * W;
-    double* o1 = a.out + b * (int64_t)H * W + (int64_t)rb * W;
-    if (add_loc && a.loc) {
-        const double* l0 = a.loc + b * a.loc_bs + (int64_t)ra * W;
-        const double* l1 = a.loc + b * a.loc_bs + (int64_t)rb * W;
-#pragma unroll
-        for (int m = 0; m < E; ++m) {
-            o0[t + T * m] = fma(alpha, v[m].x, l0[t + T * m]);
-            o1[t + T * m] = fma(alpha, v[m].y, l1[t + T * m]);
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < E; ++m) {
-            __builtin_nontemporal_store(alpha * v[m].x, o0 + t + T * m);
-            __builtin_nontemporal_store(alpha * v[m].y, o1 + t + T * m);
-        }
-    }
-}
-
 // Long rows ------------------------------------------------------------------------------------------
 // Rows of W = 2 N points whose two-for-one complex line (W points) no workgroup can hold (W = 32768: BASELINE config 5,
 // the slab passes): ONE real row is one complex line of N = W / 2 points, z[n] = x[2n] + i x[2n+1] -- a contiguous
@@ -1217,13 +994,11 @@ __global__ void __launch_bounds__(Geo<H>::COL_THREADS, 2) col_kernel(LatArgs a, 
 }
 
 template <int N> struct Launch {
-    // sub: radix of the step across rows done by the row kernels (gpt_pow2_sub.h): 0 = none (rows 2r, 2r + 1 per
-    // workgroup), 2 (rows r, r + H/2), 4 (rows r + H/4 p per workgroup of two lines; row_sub4_ok())
-    static hipError_t row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, int sub,
+    // sub2: the R = 2 sub-line variant of the row kernels (rows r and r + H/2 per workgroup)
+    static hipError_t row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, bool sub2,
                               hipStream_t st);
     static hipError_t row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
-                              const FinArgs& fin, const double* edge, int sub, hipStream_t st);
-    static bool row_sub4_ok() { return 2 * Geo<N>::T >= 256 && 2 * Geo<N>::T <= 1024; } // rows of 2048 .. 8192 points
+                              const FinArgs& fin, const double* edge, bool sub2, hipStream_t st);
     static hipError_t col(int op, const LatArgs& a, cplx* ws, int wstride, double* partials, int nwg, double* edge,
                           int edge_flags, hipStream_t st);
     // inverse rows -> observation model -> forward rows, in place (rows of up to 8192 points); its grid is

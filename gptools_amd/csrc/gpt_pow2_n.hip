@@ -35,46 +35,11 @@ hipError_t row_fwd_g(const LatArgs& a, int in_mode, cplx* ws, int wstride, doubl
 }
 } // namespace
 
-#if GPT_N >= 2048 && GPT_N <= 8192
-namespace {
-template <bool NTS>
-hipError_t row_fwd4_g(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, hipStream_t st) {
-    constexpr int W = GPT_N;
-    const size_t lds = (size_t)2 * W * sizeof(double);
-    hipError_t e = raise_lds(row_fwd4_kernel<W, NTS>, lds);
-    if (e != hipSuccess) return e;
-    if (a.H % 4) return hipErrorInvalidValue;
-    dim3 grid((unsigned)(a.H / 4), (unsigned)a.batch);
-    hipLaunchKernelGGL((row_fwd4_kernel<W, NTS>), grid, dim3(2 * Geo<W>::T), lds, st, a, in_mode, ws, wstride, edge);
-    return hipGetLastError();
-}
-hipError_t row_inv4_g(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride, const FinArgs& fin,
-                      const double* edge, hipStream_t st) {
-    constexpr int W = GPT_N;
-    const size_t lds = (size_t)2 * W * sizeof(double);
-    hipError_t e = raise_lds(row_inv4_kernel<W>, lds);
-    if (e != hipSuccess) return e;
-    if (a.H % 4) return hipErrorInvalidValue;
-    dim3 grid((unsigned)(a.H / 4), (unsigned)a.batch);
-    hipLaunchKernelGGL((row_inv4_kernel<W>), grid, dim3(2 * Geo<W>::T), lds, st, a, alpha, add_loc, ws, wstride, fin, edge);
-    return hipGetLastError();
-}
-} // namespace
-#endif
-
 template <>
-hipError_t Launch<GPT_N>::row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, int sub,
+hipError_t Launch<GPT_N>::row_fwd(const LatArgs& a, int in_mode, cplx* ws, int wstride, double* edge, bool sub2,
                                   hipStream_t st) {
     // a workspace beyond the Infinity Cache is streamed past it (see rows_st)
     const bool cold = (size_t)a.batch * (size_t)a.H * (size_t)wstride * sizeof(cplx) > ((size_t)256 << 20);
-    if (sub == 4) {
-#if GPT_N >= 2048 && GPT_N <= 8192
-        return cold ? row_fwd4_g<true>(a, in_mode, ws, wstride, edge, st) : row_fwd4_g<false>(a, in_mode, ws, wstride, edge, st);
-#else
-        return hipErrorInvalidValue;
-#endif
-    }
-    const bool sub2 = sub == 2;
     if (cold) return sub2 ? row_fwd_g<true, true>(a, in_mode, ws, wstride, edge, st)
                           : row_fwd_g<false, true>(a, in_mode, ws, wstride, edge, st);
     return sub2 ? row_fwd_g<true, false>(a, in_mode, ws, wstride, edge, st)
@@ -83,16 +48,8 @@ hipError_t Launch<GPT_N>::row_fwd(const LatArgs& a, int in_mode, cplx* ws, int w
 
 template <>
 hipError_t Launch<GPT_N>::row_inv(const LatArgs& a, double alpha, int add_loc, const cplx* ws, int wstride,
-                                  const FinArgs& fin, const double* edge, int sub, hipStream_t st) {
+                                  const FinArgs& fin, const double* edge, bool sub2, hipStream_t st) {
     constexpr int W = GPT_N;
-    if (sub == 4) {
-#if GPT_N >= 2048 && GPT_N <= 8192
-        return row_inv4_g(a, alpha, add_loc, ws, wstride, fin, edge, st);
-#else
-        return hipErrorInvalidValue;
-#endif
-    }
-    const bool sub2 = sub == 2;
     const size_t lds = (size_t)Geo<W>::ROW_LINES * W * sizeof(double);
     hipError_t e = sub2 ? raise_lds(row_inv_kernel<W, true>, lds) : raise_lds(row_inv_kernel<W, false>, lds);
     if (e != hipSuccess) return e;

@@ -76,7 +76,7 @@ static hipError_t colsub_g(const LatArgs& a, int R, cplx* ws, int wstride, const
 template <int OP>
 static hipError_t colsub_t(const LatArgs& a, int R, cplx* ws, int wstride, const cplx* tws, double* partials, int nwg,
                            double* edge, int edge_flags, hipStream_t st) {
-#if GPT_N == 2048 || GPT_N == 1024
+#if GPT_N == 2048
     // GPT_SUB_GEOM (tuning knob, same results): 1 = 256 threads (two workgroups per CU), 2 = the same with non-temporal
     // workspace accesses, 3 = 512 threads with ordinary accesses, 4 = 512 threads non-temporal; 0 / unset = the rule below
     static const int geom = [] {
@@ -87,14 +87,6 @@ static hipError_t colsub_t(const LatArgs& a, int R, cplx* ws, int wstride, const
     if (geom == 2) return colsub_g<OP, SUB_THREADS, true>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
     if (geom == 3) return colsub_g<OP, 512>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
     if (geom == 4) return colsub_g<OP, 512, true>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
-#endif
-#if GPT_N == 1024
-    // sub-lines of 1024 points (radix-4 split of 4096 rows): 8-column tiles already, two workgroups per CU; a workspace
-    // that cannot be cache-resident is streamed past the caches (pass B 99 -> 85 us)
-    if ((size_t)a.batch * (size_t)a.H * (size_t)wstride * sizeof(cplx) > ((size_t)256 << 20) && !op_is_kvjp(OP))
-        return colsub_g<OP, SUB_THREADS, true>(a, R, ws, wstride, tws, partials, nwg, edge, edge_flags, st);
-#endif
-#if GPT_N == 2048
     // 512-thread workgroups (8 columns: whole 128-byte lines of the workspace, 64-byte pieces of cov) for the ops on
     // the real z layout, and for every op when the launch's workspace cannot be cache-resident (units of many
     // lattices, gpt_api.hip): 4096^2 column pass 124.5 -> 118 us there, but 123 -> 130 us on a warm workspace.
