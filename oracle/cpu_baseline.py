@@ -24,14 +24,24 @@ import gp_oracle as oracle  # noqa: E402
 
 
 def cpu_model():
+    """Model name as /proc/cpuinfo gives it (the GPU boxes are VMs that report a bare "AMD EPYC"), with the family /
+    model numbers that identify the part behind it."""
+    name, fam, mod = "unknown", None, None
     try:
         with open("/proc/cpuinfo") as fh:
             for line in fh:
-                if line.lower().startswith("model name"):
-                    return line.split(":", 1)[1].strip()
+                key = line.split(":", 1)[0].strip().lower()
+                if key == "model name" and name == "unknown":
+                    name = line.split(":", 1)[1].strip()
+                elif key == "cpu family" and fam is None:
+                    fam = line.split(":", 1)[1].strip()
+                elif key == "model" and mod is None:
+                    mod = line.split(":", 1)[1].strip()
+                if name != "unknown" and fam is not None and mod is not None:
+                    break
     except OSError:
         pass
-    return "unknown"
+    return f"{name} (family {fam}, model {mod})" if fam is not None else name
 
 
 def usable_cores():
