@@ -13,12 +13,66 @@
 __device__ __forceinline__ unsigned fastdiv_magic(unsigned d) { return d == 1 ? 0u : 0xFFFFFFFFu / d + 1u; }
 __device__ __forceinline__ unsigned fastdiv(unsigned w, unsigned d, unsigned m) { return d == 1 ? w : __umulhi(w, m); }
 
-template <int R, bool INVERSE>
-__device__ __forceinline__ void stage_lds(const cplx* __restrict__ src, cplx* __restrict__ dst,
-                                          const cplx* __restrict__ tw, int N, int Ns, int nlines, int es, int ls) {
-    const int M = N / R, tstep = N / (Ns * R), total = nlines * M;
+// TWP: pointer type of the twiddle table w_N^m -- `const cplx*` (global memory) or LdsTw (a table the kernel copied into
+// LDS: the address space is part of the type, so that the look-ups compile to ds_read and not to flat loads).
+// The lines themselves are always in LDS and are addressed through LDS-typed pointers as well (LdsLine): through plain
+// `cplx*` the compiler could not prove it across the call and emitted flat loads / stores for every element.
+#ifndef GPT_LDS_FFT_INLINE
+#define GPT_LDS_FFT_INLINE // (gpt_small.hip: __forceinline__ -- a single small lattice is latency, and a call spills)
+#endif
+// (a small handle class rather than a bare `__attribute__((address_space(3))) cplx*`: cplx is a class type whose
+// assignment operator wants a generic `this`, which the host pass of the compiler rejects for an LDS object)
+typedef double gpt_d2 __attribute__((ext_vector_type(2)));
+struct LdsRef {
+    __attribute__((address_space(3))) gpt_d2* p;
+    __device__ __forceinline__ operator cplx() const {
+        const gpt_d2 v = *p;
+        return make_double2(v.x, v.y);
+    }
+    __device__ __forceinline__ void operator=(const cplx& v) const { *p = gpt_d2{v.x, v.y}; }
+};
+struct LdsLine {
+    __attribute__((address_space(3))) gpt_d2* p;
+    __device__ __forceinline__ LdsLine() : p(nullptr) {}
+    __device__ __forceinline__ explicit LdsLine(void* generic) : p((__attribute__((address_space(3))) gpt_d2*)generic) {}
+    __device__ __forceinline__ LdsRef operator[](int i) const { return LdsRef{p + i}; }
+    __device__ __forceinline__ LdsLine operator+(int i) const {
+        LdsLine r;
+        r.p = p + i;
+        return r;
+    }
+    __device__ __forceinline__ bool operator==(const LdsLine& o) const { return p == o.p; }
+    __device__ __forceinline__ bool operator!=(const LdsLine& o) const { return p != o.p; }
+};
+typedef LdsLine LdsTw; // a twiddle table the kernel copied into LDS
+
+// Per-stage constants of a Stockham stage: radix R over sub-transforms of length Ns done so far, M = N / R butterflies per
+// line, twiddle step N / (Ns R), and the multiply-high magics of M and Ns. Either worked out in the kernel (stage_consts:
+// one integer division each -- ~25 dependent instructions, and the optimiser hoists them for EVERY radix of the switch
+// below in front of the stage loop), or on the host once per launch (gpt_small.hip: a single small lattice is latency,
+// and these divisions were half of every stage's instructions).
+struct StageK {
+    int R, Ns, M, tstep;
+    unsigned mM, mNs;
+};
+__host__ __device__ __forceinline__ unsigned fastdiv_magic_hd(unsigned d) { return d == 1 ? 0u : 0xFFFFFFFFu / d + 1u; }
+__host__ __device__ __forceinline__ StageK stage_consts(int N, int R, int Ns) {
+    StageK k;
+    k.R = R;
+    k.Ns = Ns;
+    k.M = N / R;
+    k.tstep = N / (Ns * R);
+    k.mM = fastdiv_magic_hd((unsigned)k.M);
+    k.mNs = fastdiv_magic_hd((unsigned)Ns);
+    return k;
+}
+template <int R, bool INVERSE, typename TWP>
+__device__ __forceinline__ void stage_lds(const LdsLine src, const LdsLine dst, TWP tw, const StageK& sk, int nlines,
+                                          unsigned mL, int es, int ls) {
+    // (M = N / R, tstep = N / (Ns R) and the division magics of M, Ns, nlines arrive ready-made: see StageK)
+    const int Ns = sk.Ns, M = sk.M, tstep = sk.tstep, total = nlines * M;
+    const unsigned mM = sk.mM, mNs = sk.mNs;
     // (unrolling this loop 2-4 times so that the next butterfly's loads are issued early was measured: 10-20 % slower)
-    const unsigned mM = fastdiv_magic((unsigned)M), mNs = fastdiv_magic((unsigned)Ns), mL = fastdiv_magic((unsigned)nlines);
     // Work items are numbered so that neighbouring lanes touch neighbouring LDS addresses: along a line when its
     // elements are contiguous (es == 1: row tiles), across the lines when the lines are interleaved (ls == 1: column
     // tiles, element stride = tile width -- numbered along the line, every access of a wave was a 2- to 4-way bank
@@ -41,7 +95,7 @@ __device__ __forceinline__ void stage_lds(const cplx* __restrict__ src, cplx* __
             j = w - line * M;
         }
         const int hi = (int)fastdiv((unsigned)j, (unsigned)Ns, mNs), k = j - hi * Ns;
-        const cplx* in = src + (line * ls + j * es); // (LDS: 32-bit offsets)
+        const LdsLine in = src + (line * ls + j * es);
         cplx x[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) x[q] = in[q * M * es];
@@ -56,7 +110,7 @@ __device__ __forceinline__ void stage_lds(const cplx* __restrict__ src, cplx* __
                 x[q] = cmul(x[q], t);
             }
         }
-        cplx* out = dst + (line * ls + (hi * Ns * R + k) * es);
+        const LdsLine out = dst + (line * ls + (hi * Ns * R + k) * es);
         const int os = Ns * es;
         if constexpr (R == 2) {
             out[0] = cadd(x[0], x[1]);
@@ -117,38 +171,46 @@ __device__ __forceinline__ void stage_lds(const cplx* __restrict__ src, cplx* __
 // src[l * ls + e * es]. Radices 2, 3, 4, 5, 7, 8, 11, 13, 16 take stage_lds (8 and 16: only plans that ask for them); any other prime (e.g. 67: n = 134 = 2 * 67)
 // the generic loop below: one work item = one OUTPUT element (R complex MACs against the w_N table).
 // Returns the buffer that holds the result.
-template <bool INVERSE>
-__device__ cplx* fft_lines_lds(cplx* src, cplx* dst, const LinePlan& p, int nlines, int es, int ls) {
+//
+// stage_lds_any: one stage with ready-made constants; false: the radix has no butterfly of its own (generic loop of the caller).
+template <bool INVERSE, typename TWP>
+__device__ __forceinline__ bool stage_lds_any(LdsLine src, LdsLine dst, TWP ptw, const StageK& sk, int nlines, unsigned mL,
+                                              int es, int ls) {
+    switch (sk.R) {
+    case 2: stage_lds<2, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 3: stage_lds<3, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 4: stage_lds<4, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 5: stage_lds<5, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 7: stage_lds<7, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 8: stage_lds<8, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 16: stage_lds<16, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 11: stage_lds<11, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 13: stage_lds<13, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    default: return false;
+    }
+}
+
+// `stages`: null (constants worked out here, stage by stage) or the host-made table of the plan's p.ns stages.
+template <bool INVERSE, typename TWP>
+__device__ GPT_LDS_FFT_INLINE LdsLine fft_lines_lds_tw(LdsLine src, LdsLine dst, const LinePlan& p, TWP ptw, int nlines, int es,
+                                                       int ls, const StageK* stages = nullptr, unsigned mL_ready = 0) {
     const int N = p.n;
+    const unsigned mL = stages ? mL_ready : fastdiv_magic((unsigned)nlines);
     int Ns = 1;
     for (int s = 0; s < p.ns; ++s) {
-        const int R = p.r[s];
-        bool done = true;
-        switch (R) {
-        case 2: stage_lds<2, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
-        case 3: stage_lds<3, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
-        case 4: stage_lds<4, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
-        case 5: stage_lds<5, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
-        case 7: stage_lds<7, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
-        case 8: stage_lds<8, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
-        case 16: stage_lds<16, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
-        case 11: stage_lds<11, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
-        case 13: stage_lds<13, INVERSE>(src, dst, p.tw, N, Ns, nlines, es, ls); break;
-        default: done = false;
-        }
+        const StageK sk = stages ? stages[s] : stage_consts(N, p.r[s], Ns);
+        const int R = sk.R;
+        const bool done = stage_lds_any<INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls);
         if (done) {
             __syncthreads();
-            cplx* tmp = src;
+            LdsLine tmp = src;
             src = dst;
             dst = tmp;
             Ns *= R;
             continue;
         }
-        const int M = N / R;
-        const int tstep = N / (Ns * R);
-        const int total = nlines * N;
-        const unsigned mN = fastdiv_magic((unsigned)N), mNs = fastdiv_magic((unsigned)Ns), mR = fastdiv_magic((unsigned)R),
-                       mL = fastdiv_magic((unsigned)nlines);
+        const int M = sk.M, tstep = sk.tstep, total = nlines * N;
+        const unsigned mN = fastdiv_magic((unsigned)N), mNs = sk.mNs, mR = fastdiv_magic((unsigned)R);
         const bool across = (ls == 1 && es > 1); // (as in stage_lds)
         for (int w = threadIdx.x; w < total; w += blockDim.x) {
             int line, o;
@@ -165,12 +227,12 @@ __device__ cplx* fft_lines_lds(cplx* src, cplx* dst, const LinePlan& p, int nlin
             const int pp = t - th * R;
             const int j = th * Ns + k;
             const int base = (int)(((int64_t)k * tstep + (int64_t)pp * M) % N);
-            const cplx* in = src + (line * ls + j * es);
+            const LdsLine in = src + (line * ls + j * es);
             double ar = 0.0, ai = 0.0;
             int e = 0;
             for (int q = 0; q < R; ++q) {
                 const cplx v = in[q * M * es];
-                cplx tw = p.tw[e];
+                cplx tw = ptw[e];
                 if (INVERSE) tw.y = -tw.y;
                 ar = fma(v.x, tw.x, ar);
                 ar = fma(-v.y, tw.y, ar);
@@ -182,7 +244,7 @@ __device__ cplx* fft_lines_lds(cplx* src, cplx* dst, const LinePlan& p, int nlin
             dst[line * ls + o * es] = make_double2(ar, ai);
         }
         __syncthreads();
-        cplx* tmp = src;
+        LdsLine tmp = src;
         src = dst;
         dst = tmp;
         Ns *= R;
@@ -190,3 +252,9 @@ __device__ cplx* fft_lines_lds(cplx* src, cplx* dst, const LinePlan& p, int nlin
     return src;
 }
 
+// twiddles where the plan has them (global memory)
+template <bool INVERSE>
+__device__ cplx* fft_lines_lds(cplx* src, cplx* dst, const LinePlan& p, int nlines, int es, int ls) {
+    const LdsLine r = fft_lines_lds_tw<INVERSE, const cplx*>(LdsLine(src), LdsLine(dst), p, p.tw, nlines, es, ls);
+    return r == LdsLine(src) ? src : dst;
+}

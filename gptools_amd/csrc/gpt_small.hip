@@ -12,34 +12,89 @@
 //   ew     op-specific elementwise stage (gpt_common.h), wave/workgroup reduction for the log density
 //   cols^-1, merge row pairs, rows^-1, store
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 
 #include "gpt_common.h"
 #include "gpt_host.h"
+// The line transforms are inlined here (nowhere else): as a called function the stage loop took its plan through a stack
+// copy, spilled 13-44 VGPRs around each of the four calls and read scratch back before every phase -- all of it latency on
+// a path that is nothing but latency (one 35 x 60 lattice: ~20 barrier-separated phases).
+#define GPT_LDS_FFT_INLINE __forceinline__
 #include "gpt_lds_fft.h"
+
+// GPT_SMALL_STAMPS (a variant build, scripts/small_stamps.py): workgroup 0 leaves the cycle counter at every phase boundary
+#ifdef GPT_SMALL_STAMPS
+__device__ long long gpt_small_stamps[32];
+#define STAMP(k)                                                                                                      \
+    do {                                                                                                              \
+        if (stamp_on_ && blockIdx.x == 0 && threadIdx.x == 0) gpt_small_stamps[k] = (k) >= 16 ? wall_clock64() : __builtin_readcyclecounter(); \
+    } while (0)
+extern "C" int gpt_debug_small_stamps(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gpt_small_stamps), (size_t)n * sizeof(long long));
+}
+#else
+#define STAMP(k)
+#endif
 
 namespace {
 
-template <int OP>
-__global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap, int sS) {
+// Stage constants of the two line plans, made on the host once per launch (StageK, gpt_lds_fft.h), and the division magics
+// of the two line counts: (H + 1) / 2 row pairs, 1 + (W - 1) / 2 packed columns.
+struct SmallStages {
+    StageK w[GPT_MAX_STAGES], h[GPT_MAX_STAGES];
+    unsigned mLw, mLh;
+    unsigned mW, mNC, mwc; // magics of the element loops: W, NC = 1 + (W - 1) / 2, max((W - 1) / 2, 1)
+};
+
+template <int OP, bool TWL>
+__global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap, int sS, SmallStages ss) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef GPT_SMALL_STAMPS
+    // GPT_SMALL_STAMPS=2: the whole body twice, stamps from the second time round (instruction cache warm)
+    for (int rep_ = 0; rep_ < GPT_SMALL_STAMPS; ++rep_) {
+    const bool stamp_on_ = rep_ == GPT_SMALL_STAMPS - 1;
+    __syncthreads();
+#endif
     double* red = reinterpret_cast<double*>(smem); // 64 doubles
-    cplx* buf0 = reinterpret_cast<cplx*>(smem + 512);
-    cplx* buf1 = buf0 + cap;
+    // (LDS-typed pointers, gpt_lds_fft.h: every access below is a ds_read / ds_write, never a flat one)
+    const LdsLine buf0(smem + 512);
+    const LdsLine buf1 = buf0 + cap;
     const int64_t b = blockIdx.x;
     const int H = a.H, W = a.W;
+    STAMP(0);
+    STAMP(16);
     const ZLayout L = make_layout(a);
     EwPtrs P = make_ptrs(a, b);
     kern_prepare<OP>(a, P);
     const int NC = 1 + L.wc;
     const int Hp = (H + 1) / 2;
     const bool weven = (W % 2) == 0;
-    cplx* cur = buf0;
-    cplx* oth = buf1;
+    LdsLine cur = buf0;
+    LdsLine oth = buf1;
     // (index arithmetic of the element loops: multiply-high instead of integer division, gpt_lds_fft.h)
-    const unsigned mW = fastdiv_magic((unsigned)W), mNC = fastdiv_magic((unsigned)NC),
-                   mwc = fastdiv_magic((unsigned)(L.wc > 0 ? L.wc : 1));
+    const unsigned mW = ss.mW, mNC = ss.mNC, mwc = ss.mwc;
+    // Twiddle tables in LDS (TWL: they fit behind the two line buffers; a template flag so that the look-ups compile to
+    // LDS reads, not to flat loads): every Stockham stage looks its twiddles up,
+    // and with the tables in global memory each of the ~10 stages of a small lattice started with a dependent global
+    // load (a single 35 x 60 lattice is pure latency: ~20 barrier-separated phases).
+    const LdsLine tws = buf0 + 2 * cap;
+    if (TWL) {
+        for (int i = threadIdx.x; i < W; i += blockDim.x) tws[i] = a.pw.tw[i];
+        for (int i = threadIdx.x; i < H; i += blockDim.x) tws[W + i] = a.ph.tw[i];
+        // (every path below reaches a __syncthreads() before its first transform)
+    }
+    // line transforms with the twiddles of the row / column plan, from LDS or from the plan's own table
+    auto fft_w = [&](auto inv, LdsLine src, LdsLine dst, int nl, int es, int ls) -> LdsLine {
+        if constexpr (TWL) return fft_lines_lds_tw<decltype(inv)::value, LdsTw>(src, dst, a.pw, tws, nl, es, ls, ss.w, ss.mLw);
+        else return fft_lines_lds_tw<decltype(inv)::value, const cplx*>(src, dst, a.pw, a.pw.tw, nl, es, ls, ss.w, ss.mLw);
+    };
+    auto fft_h = [&](auto inv, LdsLine src, LdsLine dst, int nl, int es, int ls) -> LdsLine {
+        if constexpr (TWL) return fft_lines_lds_tw<decltype(inv)::value, LdsTw>(src, dst, a.ph, tws + W, nl, es, ls, ss.h, ss.mLh);
+        else return fft_lines_lds_tw<decltype(inv)::value, const cplx*>(src, dst, a.ph, a.ph.tw, nl, es, ls, ss.h, ss.mLh);
+    };
 
+    STAMP(1);
     if (op_has_fwd(OP)) {
         // load: line r = rows (2r, 2r+1)
         for (int w = threadIdx.x; w < Hp * W; w += blockDim.x) {
@@ -49,15 +104,17 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
             cur[w] = make_double2(re, im);
         }
         __syncthreads();
-        cplx* res = fft_lines_lds<false>(cur, oth, a.pw, Hp, 1, W);
+        STAMP(2);
+        LdsLine res = fft_w(std::false_type{}, cur, oth, Hp, 1, W);
         if (res != cur) {
             oth = cur;
             cur = res;
         }
+        STAMP(3);
         // split row pairs -> packed spectrum S[i * sS + jp] in `oth`
         for (int w = threadIdx.x; w < H * NC; w += blockDim.x) {
             const int i = (int)fastdiv((unsigned)w, (unsigned)NC, mNC), jp = w - i * NC;
-            const cplx* line = cur + (i >> 1) * W;
+            const LdsLine line = cur + (i >> 1) * W;
             auto rowspec = [&](int j) -> cplx {
                 const cplx z = line[j];
                 const cplx zc = line[j == 0 ? 0 : W - j];
@@ -76,15 +133,17 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         }
         __syncthreads();
         {
-            cplx* t = cur;
+            const LdsLine t = cur;
             cur = oth;
             oth = t;
         }
-        res = fft_lines_lds<false>(cur, oth, a.ph, NC, sS, 1);
+        STAMP(4);
+        res = fft_h(std::false_type{}, cur, oth, NC, sS, 1);
         if (res != cur) {
             oth = cur;
             cur = res;
         }
+        STAMP(5);
     }
 
     // elementwise stage on S = cur
@@ -98,8 +157,9 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         acc_renorm(acc);
     }
     acc_fold(acc);
+    STAMP(6);
     for (int k = threadIdx.x; k <= H / 2; k += blockDim.x) {
-        const int km = (H - k) % H;
+        const int km = k ? H - k : 0; // (H - k) % H
         cplx Zk = cur[k * sS], Zm = cur[km * sS];
         ew_packed0<OP>(a, L, P, k, Zk, Zm, acc);
         if (op_has_inv(OP)) {
@@ -107,6 +167,7 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
             if (km != k) cur[km * sS] = Zm;
         }
     }
+    STAMP(7);
     if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
         double s = acc.sum, m = acc.mn;
         double kk[3] = {acc.k0, acc.k1, acc.k2};
@@ -132,13 +193,15 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         }
     }
     __syncthreads();
+    STAMP(8);
 
     if (op_has_inv(OP)) {
-        cplx* res = fft_lines_lds<true>(cur, oth, a.ph, NC, sS, 1);
+        LdsLine res = fft_h(std::true_type{}, cur, oth, NC, sS, 1);
         if (res != cur) {
             oth = cur;
             cur = res;
         }
+        STAMP(9);
         // merge row pairs into complex lines of length W in `oth`
         for (int w = threadIdx.x; w < Hp * W; w += blockDim.x) {
             const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
@@ -146,8 +209,8 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
                 const bool mir = jj > W / 2;
                 const int q = mir ? W - jj : jj;
                 cplx v;
-                if (q == 0) v = make_double2(cur[i * sS].x, 0.0);
-                else if (weven && q == W / 2) v = make_double2(cur[i * sS].y, 0.0);
+                if (q == 0) v = make_double2(cplx(cur[i * sS]).x, 0.0);
+                else if (weven && q == W / 2) v = make_double2(cplx(cur[i * sS]).y, 0.0);
                 else v = cur[i * sS + q];
                 if (mir) v.y = -v.y;
                 return v;
@@ -159,11 +222,13 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         }
         __syncthreads();
         {
-            cplx* t = cur;
+            const LdsLine t = cur;
             cur = oth;
             oth = t;
         }
-        res = fft_lines_lds<true>(cur, oth, a.pw, Hp, 1, W);
+        STAMP(10);
+        res = fft_w(std::true_type{}, cur, oth, Hp, 1, W);
+        STAMP(11);
         for (int w = threadIdx.x; w < Hp * W; w += blockDim.x) {
             const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
             const cplx v = res[w];
@@ -172,10 +237,29 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
             if (2 * r + 1 < H) o[(int64_t)(2 * r + 1) * W + j] = out_transform<OP>(a, b, 2 * r + 1, j, v.y);
         }
     }
+    STAMP(12);
+    STAMP(17);
+#ifdef GPT_SMALL_STAMPS
+    }
+#endif
 }
 
-template <int OP>
-hipError_t launch_small_t(const LatArgs& a, int cap, int sS, int nthreads, size_t lds, hipStream_t st) {
+template <int OP, bool TWL>
+hipError_t launch_small_v(const LatArgs& a, int cap, int sS, int nthreads, size_t lds, hipStream_t st) {
+    SmallStages ss;
+    auto fill = [](const LinePlan& p, StageK* k) {
+        int Ns = 1;
+        for (int s = 0; s < p.ns && s < GPT_MAX_STAGES; ++s) {
+            k[s] = stage_consts(p.n, p.r[s], Ns);
+            Ns *= p.r[s];
+        }
+    };
+    fill(a.pw, ss.w);
+    fill(a.ph, ss.h);
+    ss.mLw = fastdiv_magic_hd((unsigned)((a.H + 1) / 2));
+    ss.mLh = ss.mNC = fastdiv_magic_hd((unsigned)(1 + (a.W - 1) / 2));
+    ss.mW = fastdiv_magic_hd((unsigned)a.W);
+    ss.mwc = fastdiv_magic_hd((unsigned)((a.W - 1) / 2 > 0 ? (a.W - 1) / 2 : 1));
     // The attribute belongs to (kernel, device): one bit per device, set from any thread (raising the cap twice is
     // harmless, so a lost race costs one extra call).
     static std::atomic<uint64_t> attr_set{0};
@@ -184,13 +268,18 @@ hipError_t launch_small_t(const LatArgs& a, int cap, int sS, int nthreads, size_
     if (e != hipSuccess) return e;
     const uint64_t bit = dev < 64 ? (uint64_t)1 << dev : 0;
     if (lds > 64 * 1024 && !(attr_set.load(std::memory_order_relaxed) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_lattice_kernel<OP>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_lattice_kernel<OP, TWL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(small_lattice_kernel<OP>, dim3((unsigned)a.batch), dim3(nthreads), lds, st, a, cap, sS);
+    hipLaunchKernelGGL((small_lattice_kernel<OP, TWL>), dim3((unsigned)a.batch), dim3(nthreads), lds, st, a, cap, sS, ss);
     return hipGetLastError();
+}
+template <int OP>
+hipError_t launch_small_t(const LatArgs& a, int cap, int sS, int nthreads, size_t lds, int tw_lds, hipStream_t st) {
+    return tw_lds ? launch_small_v<OP, true>(a, cap, sS, nthreads, lds, st)
+                  : launch_small_v<OP, false>(a, cap, sS, nthreads, lds, st);
 }
 
 } // namespace
@@ -210,7 +299,12 @@ hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st) {
     int cap, sS;
     if (!gpt_small_fits(a.H, a.W, &cap, &sS)) return hipErrorInvalidValue;
     if (a.batch <= 0) return hipSuccess;
-    const size_t lds = 512 + 2 * (size_t)cap * sizeof(cplx);
+    size_t lds = 512 + 2 * (size_t)cap * sizeof(cplx);
+    // the two twiddle tables ride in LDS when there is room behind the line buffers (GPT_SMALL_TW_LDS=0: A/B timing)
+    static const bool tw_off = [] { const char* e = getenv("GPT_SMALL_TW_LDS"); return e && e[0] == '0'; }();
+    const size_t tw_bytes = ((size_t)a.H + (size_t)a.W) * sizeof(cplx);
+    const int tw_lds = (!tw_off && lds + tw_bytes <= 160 * 1024) ? 1 : 0;
+    if (tw_lds) lds += tw_bytes;
     int64_t work = (int64_t)a.H * a.W / 4;
     int nthreads = (int)((work + 63) / 64 * 64);
     if (nthreads < 64) nthreads = 64;
@@ -224,17 +318,17 @@ hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st) {
     }();
     if (forced >= 64 && forced <= 1024) nthreads = forced / 64 * 64;
     switch (op) {
-    case OP_RFFT2: return launch_small_t<OP_RFFT2>(a, cap, sS, nthreads, lds, st);
-    case OP_INV_RFFT2: return launch_small_t<OP_INV_RFFT2>(a, cap, sS, nthreads, lds, st);
-    case OP_GP_RFFT2: return launch_small_t<OP_GP_RFFT2>(a, cap, sS, nthreads, lds, st);
-    case OP_GP_INV_RFFT2: return launch_small_t<OP_GP_INV_RFFT2>(a, cap, sS, nthreads, lds, st);
-    case OP_LPDF: return launch_small_t<OP_LPDF>(a, cap, sS, nthreads, lds, st);
-    case OP_LPDF_VJP: return launch_small_t<OP_LPDF_VJP>(a, cap, sS, nthreads, lds, st);
-    case OP_INV_VJP: return launch_small_t<OP_INV_VJP>(a, cap, sS, nthreads, lds, st);
-    case OP_FWD_VJP: return launch_small_t<OP_FWD_VJP>(a, cap, sS, nthreads, lds, st);
-    case OP_LPDF_VJP_NOCOV: return launch_small_t<OP_LPDF_VJP_NOCOV>(a, cap, sS, nthreads, lds, st);
-    case OP_LPDF_KVJP: return launch_small_t<OP_LPDF_KVJP>(a, cap, sS, nthreads, lds, st);
-    case OP_LPDF_KVJP_EQ: return launch_small_t<OP_LPDF_KVJP_EQ>(a, cap, sS, nthreads, lds, st);
+    case OP_RFFT2: return launch_small_t<OP_RFFT2>(a, cap, sS, nthreads, lds, tw_lds, st);
+    case OP_INV_RFFT2: return launch_small_t<OP_INV_RFFT2>(a, cap, sS, nthreads, lds, tw_lds, st);
+    case OP_GP_RFFT2: return launch_small_t<OP_GP_RFFT2>(a, cap, sS, nthreads, lds, tw_lds, st);
+    case OP_GP_INV_RFFT2: return launch_small_t<OP_GP_INV_RFFT2>(a, cap, sS, nthreads, lds, tw_lds, st);
+    case OP_LPDF: return launch_small_t<OP_LPDF>(a, cap, sS, nthreads, lds, tw_lds, st);
+    case OP_LPDF_VJP: return launch_small_t<OP_LPDF_VJP>(a, cap, sS, nthreads, lds, tw_lds, st);
+    case OP_INV_VJP: return launch_small_t<OP_INV_VJP>(a, cap, sS, nthreads, lds, tw_lds, st);
+    case OP_FWD_VJP: return launch_small_t<OP_FWD_VJP>(a, cap, sS, nthreads, lds, tw_lds, st);
+    case OP_LPDF_VJP_NOCOV: return launch_small_t<OP_LPDF_VJP_NOCOV>(a, cap, sS, nthreads, lds, tw_lds, st);
+    case OP_LPDF_KVJP: return launch_small_t<OP_LPDF_KVJP>(a, cap, sS, nthreads, lds, tw_lds, st);
+    case OP_LPDF_KVJP_EQ: return launch_small_t<OP_LPDF_KVJP_EQ>(a, cap, sS, nthreads, lds, tw_lds, st);
     default: return hipErrorInvalidValue;
     }
 }
