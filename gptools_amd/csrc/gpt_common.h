@@ -619,34 +619,27 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
             ret = make_double2(P.x[zr] * se, P.x[zi] * se);
         }
     } else if (OP == OP_LPDF || op_is_lpdf_vjp(OP)) {
+        // One straight line for real points (weight 1/2, only Re counts) and complex pairs (weight 1): a wave that holds
+        // both kinds -- every wave of the one-workgroup path does -- used to run the division and the logarithm twice,
+        // once per arm. Same operations in the same order as the two arms had, so the results are bit for bit the same.
         const double inv_c = 1.0 / c;
-        if (real_pt) {
-            const double q = FA.x * FA.x * inv_c / n;
-            acc.sum -= 0.5 * (q + log(c));
-            if (op_is_lpdf_vjp(OP)) {
-                if (OP == OP_LPDF_VJP) {
-                    if (P.edge_dcov) P.edge_dcov[(j ? a.H : 0) + k] = 0.5 * (q - 1.0) * inv_c;
-                    else P.out_cov[ck] = 0.5 * (q - 1.0) * inv_c;
+        const double f2 = real_pt ? FA.x * FA.x : fma(FA.x, FA.x, FA.y * FA.y);
+        const double q = f2 * inv_c / n;
+        const double wgt = real_pt ? 0.5 : 1.0;
+        acc.sum -= wgt * (q + log(c));
+        if (op_is_lpdf_vjp(OP)) {
+            const double cbar = wgt * (q - 1.0) * inv_c;
+            if (OP == OP_LPDF_VJP) {
+                if (P.edge_dcov) {
+                    P.edge_dcov[(j ? a.H : 0) + k] = cbar;
+                    if (!real_pt) P.edge_dcov[(j ? a.H : 0) + km] = 0.0;
+                } else {
+                    P.out_cov[ck] = cbar;
+                    if (!real_pt) P.out_cov[cm_] = 0.0;
                 }
-                if (op_is_kvjp(OP)) acc_kern(acc, kv, 0.5 * (q - 1.0) * inv_c);
-                ret = make_double2(FA.x * inv_c, 0.0);
             }
-        } else {
-            const double q = fma(FA.x, FA.x, FA.y * FA.y) * inv_c / n;
-            acc.sum -= q + log(c);
-            if (op_is_lpdf_vjp(OP)) {
-                if (OP == OP_LPDF_VJP) {
-                    if (P.edge_dcov) {
-                        P.edge_dcov[(j ? a.H : 0) + k] = (q - 1.0) * inv_c;
-                        P.edge_dcov[(j ? a.H : 0) + km] = 0.0;
-                    } else {
-                        P.out_cov[ck] = (q - 1.0) * inv_c;
-                        P.out_cov[cm_] = 0.0;
-                    }
-                }
-                if (op_is_kvjp(OP)) acc_kern(acc, kv, (q - 1.0) * inv_c);
-                ret = cscale(FA, inv_c);
-            }
+            if (op_is_kvjp(OP)) acc_kern(acc, kv, cbar);
+            ret = make_double2(FA.x * inv_c, real_pt ? 0.0 : FA.y * inv_c);
         }
     } else if (OP == OP_INV_VJP) {
         const double k1 = 1.0 / n;

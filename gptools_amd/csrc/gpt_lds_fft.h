@@ -13,10 +13,42 @@
 __device__ __forceinline__ unsigned fastdiv_magic(unsigned d) { return d == 1 ? 0u : 0xFFFFFFFFu / d + 1u; }
 __device__ __forceinline__ unsigned fastdiv(unsigned w, unsigned d, unsigned m) { return d == 1 ? w : __umulhi(w, m); }
 
+// cos / sin of 2 pi m / R for the odd prime radices with a butterfly of their own (m any integer; folded at compile time)
+template <int R> struct constexpr_root {
+    double c, s;
+    __host__ __device__ constexpr constexpr_root(int m) : c(0.0), s(0.0) {
+        constexpr double C7[3] = {0.62348980185873359439, -0.22252093395631433737, -0.90096886790241903498};
+        constexpr double S7[3] = {0.78183148246802980363, 0.97492791218182361934, 0.43388373911755823142};
+        constexpr double C11[5] = {0.84125353283118120551, 0.41541501300188643508, -0.14231483827328500480,
+                                   -0.65486073394528498959, -0.95949297361449736865};
+        constexpr double S11[5] = {0.54064081745559755543, 0.90963199535451833011, 0.98982144188093279524,
+                                   0.75574957435425826890, 0.28173255684142967104};
+        constexpr double C13[6] = {0.88545602565320991051, 0.56806474673115592289, 0.12053668025532300601,
+                                   -0.35460488704253545489, -0.74851074817110119231, -0.97094181742605201180};
+        constexpr double S13[6] = {0.46472317204376850652, 0.82298386589365635224, 0.99270887409805397272,
+                                   0.93501624268541483342, 0.66312265824079519305, 0.23931566428755768339};
+        static_assert(R == 7 || R == 11 || R == 13, "radix without a root table");
+        m %= R;
+        const bool refl = m > (R - 1) / 2; // cos(2 pi (R - m) / R) = cos(2 pi m / R), sin changes sign
+        const int k = refl ? R - m : m;
+        if (k == 0) {
+            c = 1.0;
+            s = 0.0;
+        } else {
+            c = R == 7 ? C7[(k - 1) % 3] : R == 11 ? C11[(k - 1) % 5] : C13[(k - 1) % 6];
+            s = R == 7 ? S7[(k - 1) % 3] : R == 11 ? S11[(k - 1) % 5] : S13[(k - 1) % 6];
+            if (refl) s = -s;
+        }
+    }
+};
+
 // TWP: pointer type of the twiddle table w_N^m -- `const cplx*` (global memory) or LdsTw (a table the kernel copied into
 // LDS: the address space is part of the type, so that the look-ups compile to ds_read and not to flat loads).
 // The lines themselves are always in LDS and are addressed through LDS-typed pointers as well (LdsLine): through plain
 // `cplx*` the compiler could not prove it across the call and emitted flat loads / stores for every element.
+#ifndef GPT_STAGE_STAMP
+#define GPT_STAGE_STAMP(R) // (diagnostic build of gpt_small.hip: cycle counter after every stage)
+#endif
 #ifndef GPT_LDS_FFT_INLINE
 #define GPT_LDS_FFT_INLINE // (gpt_small.hip: __forceinline__ -- a single small lattice is latency, and a call spills)
 #endif
@@ -78,12 +110,6 @@ __device__ __forceinline__ void stage_lds(const LdsLine src, const LdsLine dst, 
     // tiles, element stride = tile width -- numbered along the line, every access of a wave was a 2- to 4-way bank
     // conflict).
     const bool across = (ls == 1 && es > 1);
-    cplx wr[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        wr[r] = tw[r * M];
-        if (INVERSE) wr[r].y = -wr[r].y;
-    }
 #pragma unroll 1
     for (int w = threadIdx.x; w < total; w += blockDim.x) {
         int line, j;
@@ -152,16 +178,35 @@ __device__ __forceinline__ void stage_lds(const LdsLine src, const LdsLine dst, 
 #pragma unroll
             for (int p = 0; p < R; ++p) out[p * os] = x[p];
         } else {
+            // odd prime radix (7, 11, 13), inputs paired about the middle: with s_q = x_q + x_{R-q}, d_q = x_q - x_{R-q},
+            //   X_p = a_p -+ i b_p,  X_{R-p} = a_p +- i b_p,  a_p = x_0 + sum_q s_q cos(2 pi p q / R),  b_p = sum_q d_q sin(...)
+            // -- (R - 1)^2 real multiply-adds instead of the 4 (R - 1)^2 of the plain R-point sum
+            constexpr int h = (R - 1) / 2;
+            cplx sq[h], dq[h];
 #pragma unroll
-            for (int p = 0; p < R; ++p) {
-                cplx acc = x[0];
+            for (int q = 1; q <= h; ++q) {
+                sq[q - 1] = cadd(x[q], x[R - q]);
+                dq[q - 1] = csub(x[q], x[R - q]);
+            }
+            cplx o0 = x[0];
 #pragma unroll
-                for (int q = 1; q < R; ++q) {
-                    const cplx t = wr[(p * q) % R];
-                    acc.x = fma(x[q].x, t.x, fma(-x[q].y, t.y, acc.x));
-                    acc.y = fma(x[q].x, t.y, fma(x[q].y, t.x, acc.y));
+            for (int q = 0; q < h; ++q) o0 = cadd(o0, sq[q]);
+            out[0] = o0;
+#pragma unroll
+            for (int p = 1; p <= h; ++p) {
+                cplx av = x[0], bv = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int q = 1; q <= h; ++q) {
+                    constexpr_root<R> rt(p * q);
+                    av.x = fma(sq[q - 1].x, rt.c, av.x);
+                    av.y = fma(sq[q - 1].y, rt.c, av.y);
+                    bv.x = fma(dq[q - 1].x, rt.s, bv.x);
+                    bv.y = fma(dq[q - 1].y, rt.s, bv.y);
                 }
-                out[p * os] = acc;
+                // forward: X_p = a - i b, X_{R-p} = a + i b (inverse: the other way round)
+                const cplx lo = make_double2(av.x + bv.y, av.y - bv.x), hi2 = make_double2(av.x - bv.y, av.y + bv.x);
+                out[p * os] = INVERSE ? hi2 : lo;
+                out[(R - p) * os] = INVERSE ? lo : hi2;
             }
         }
     }
@@ -203,6 +248,7 @@ __device__ GPT_LDS_FFT_INLINE LdsLine fft_lines_lds_tw(LdsLine src, LdsLine dst,
         const bool done = stage_lds_any<INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls);
         if (done) {
             __syncthreads();
+            GPT_STAGE_STAMP(R);
             LdsLine tmp = src;
             src = dst;
             dst = tmp;

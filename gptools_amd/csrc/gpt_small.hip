@@ -17,15 +17,29 @@
 
 #include "gpt_common.h"
 #include "gpt_host.h"
-// The line transforms are inlined here (nowhere else): as a called function the stage loop took its plan through a stack
-// copy, spilled 13-44 VGPRs around each of the four calls and read scratch back before every phase -- all of it latency on
-// a path that is nothing but latency (one 35 x 60 lattice: ~20 barrier-separated phases).
-#define GPT_LDS_FFT_INLINE __forceinline__
-#include "gpt_lds_fft.h"
-
 // GPT_SMALL_STAMPS (a variant build, scripts/small_stamps.py): workgroup 0 leaves the cycle counter at every phase boundary
 #ifdef GPT_SMALL_STAMPS
 __device__ long long gpt_small_stamps[32];
+// ... and after every Stockham stage: [0] = number of entries, then (radix, cycle counter) pairs
+__device__ long long gpt_small_stage_stamps[64];
+// (every stage stamp costs a global round trip on the critical path -- GPT_SMALL_STAMPS=3 only: the totals of such a
+// run are not those of the kernel)
+#define GPT_STAGE_STAMP(R)                                                                                            \
+    do {                                                                                                              \
+        if (GPT_SMALL_STAMPS >= 3 && blockIdx.x == 0 && threadIdx.x == 0) {                                                                    \
+            const long long i_ = gpt_small_stage_stamps[0];                                                           \
+            if (i_ < 31) {                                                                                            \
+                gpt_small_stage_stamps[1 + 2 * i_] = (R);                                                             \
+                gpt_small_stage_stamps[2 + 2 * i_] = __builtin_readcyclecounter();                                    \
+                gpt_small_stage_stamps[0] = i_ + 1;                                                                   \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+// (the same from the workgroup's LAST thread: the waves at the tail run the packed column)
+#define STAMP_LAST(k)                                                                                                 \
+    do {                                                                                                              \
+        if (stamp_on_ && blockIdx.x == 0 && threadIdx.x == blockDim.x - 1) gpt_small_stamps[k] = __builtin_readcyclecounter(); \
+    } while (0)
 #define STAMP(k)                                                                                                      \
     do {                                                                                                              \
         if (stamp_on_ && blockIdx.x == 0 && threadIdx.x == 0) gpt_small_stamps[k] = (k) >= 16 ? wall_clock64() : __builtin_readcyclecounter(); \
@@ -33,9 +47,21 @@ __device__ long long gpt_small_stamps[32];
 extern "C" int gpt_debug_small_stamps(long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gpt_small_stamps), (size_t)n * sizeof(long long));
 }
+extern "C" int gpt_debug_small_stage_stamps(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gpt_small_stage_stamps), (size_t)n * sizeof(long long));
+}
 #else
 #define STAMP(k)
+#define STAMP_LAST(k)
 #endif
+
+// The line transforms are inlined here (nowhere else): as a called function the stage loop took its plan through a stack
+// copy, spilled 13-44 VGPRs around each of the four calls and read scratch back before every phase -- all of it latency on
+// a path that is nothing but latency (one 35 x 60 lattice: ~20 barrier-separated phases).
+#define GPT_LDS_FFT_INLINE __forceinline__
+#include "gpt_lds_fft.h"
+
+#define GPT_SMALL_HDR 1024 // bytes of LDS in front of the two line buffers (the reduction's per-wave slots)
 
 namespace {
 
@@ -47,7 +73,7 @@ struct SmallStages {
     unsigned mW, mNC, mwc; // magics of the element loops: W, NC = 1 + (W - 1) / 2, max((W - 1) / 2, 1)
 };
 
-template <int OP, bool TWL>
+template <int OP>
 __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap, int sS, SmallStages ss) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef GPT_SMALL_STAMPS
@@ -56,17 +82,23 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
     const bool stamp_on_ = rep_ == GPT_SMALL_STAMPS - 1;
     __syncthreads();
 #endif
-    double* red = reinterpret_cast<double*>(smem); // 64 doubles
+    double* red = reinterpret_cast<double*>(smem); // 5 x 16 doubles (GPT_SMALL_HDR bytes)
     // (LDS-typed pointers, gpt_lds_fft.h: every access below is a ds_read / ds_write, never a flat one)
-    const LdsLine buf0(smem + 512);
+    const LdsLine buf0(smem + GPT_SMALL_HDR);
     const LdsLine buf1 = buf0 + cap;
     const int64_t b = blockIdx.x;
     const int H = a.H, W = a.W;
     STAMP(0);
     STAMP(16);
+#ifdef GPT_SMALL_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) gpt_small_stage_stamps[0] = 0;
+#endif
     const ZLayout L = make_layout(a);
-    EwPtrs P = make_ptrs(a, b);
-    kern_prepare<OP>(a, P);
+    // (the per-lattice pointers are made where the elementwise stage starts, not here: fewer scalar registers alive across
+    // the transforms, which spill otherwise. The kernel-fused ops need theirs now: kern_prepare's loads and divisions
+    // then overlap with the forward transform.)
+    EwPtrs P_early = make_ptrs(a, b);
+    if (op_is_kvjp(OP)) kern_prepare<OP>(a, P_early);
     const int NC = 1 + L.wc;
     const int Hp = (H + 1) / 2;
     const bool weven = (W % 2) == 0;
@@ -74,26 +106,33 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
     LdsLine oth = buf1;
     // (index arithmetic of the element loops: multiply-high instead of integer division, gpt_lds_fft.h)
     const unsigned mW = ss.mW, mNC = ss.mNC, mwc = ss.mwc;
-    // Twiddle tables in LDS (TWL: they fit behind the two line buffers; a template flag so that the look-ups compile to
-    // LDS reads, not to flat loads): every Stockham stage looks its twiddles up,
-    // and with the tables in global memory each of the ~10 stages of a small lattice started with a dependent global
-    // load (a single 35 x 60 lattice is pure latency: ~20 barrier-separated phases).
-    const LdsLine tws = buf0 + 2 * cap;
-    if (TWL) {
-        for (int i = threadIdx.x; i < W; i += blockDim.x) tws[i] = a.pw.tw[i];
-        for (int i = threadIdx.x; i < H; i += blockDim.x) tws[W + i] = a.ph.tw[i];
-        // (every path below reaches a __syncthreads() before its first transform)
-    }
-    // line transforms with the twiddles of the row / column plan, from LDS or from the plan's own table
+    // (Twiddle tables copied into LDS behind the line buffers were measured, profiles/r03_k_small_tw_lds_ab.jsonl: no faster --
+    // 16.30 against 16.24 us for one 35 x 60 lattice, 0.4 us slower for the 1-D sizes -- so they stay where the plan has them.)
     auto fft_w = [&](auto inv, LdsLine src, LdsLine dst, int nl, int es, int ls) -> LdsLine {
-        if constexpr (TWL) return fft_lines_lds_tw<decltype(inv)::value, LdsTw>(src, dst, a.pw, tws, nl, es, ls, ss.w, ss.mLw);
-        else return fft_lines_lds_tw<decltype(inv)::value, const cplx*>(src, dst, a.pw, a.pw.tw, nl, es, ls, ss.w, ss.mLw);
+        return fft_lines_lds_tw<decltype(inv)::value, const cplx*>(src, dst, a.pw, a.pw.tw, nl, es, ls, ss.w, ss.mLw);
     };
     auto fft_h = [&](auto inv, LdsLine src, LdsLine dst, int nl, int es, int ls) -> LdsLine {
-        if constexpr (TWL) return fft_lines_lds_tw<decltype(inv)::value, LdsTw>(src, dst, a.ph, tws + W, nl, es, ls, ss.h, ss.mLh);
-        else return fft_lines_lds_tw<decltype(inv)::value, const cplx*>(src, dst, a.ph, a.ph.tw, nl, es, ls, ss.h, ss.mLh);
+        return fft_lines_lds_tw<decltype(inv)::value, const cplx*>(src, dst, a.ph, a.ph.tw, nl, es, ls, ss.h, ss.mLh);
     };
 
+    // cov of this thread's first elementwise entries, asked for now: by the time the transforms are through they are in
+    // registers, instead of a memory round trip in the middle of the kernel
+    constexpr bool USES_COV = OP != OP_RFFT2 && OP != OP_INV_RFFT2 && !op_is_kvjp(OP);
+    const int tail = (int)blockDim.x - 1 - (int)threadIdx.x; // work item of the packed-column loop: (row k, edge column)
+    double pre_ci = 1.0, pre_c = 1.0, pre_cm = 1.0;
+    if (USES_COV) {
+        const double* cov_b = a.cov + b * a.cov_bs;
+        if ((int)threadIdx.x < H * L.wc) {
+            const int i = (int)fastdiv(threadIdx.x, (unsigned)L.wc, mwc), j = 1 + ((int)threadIdx.x - i * L.wc);
+            pre_ci = cov_b[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
+        }
+        const int k = tail >> 1, e = tail & 1;
+        if (k <= H / 2 && (e == 0 || weven)) {
+            const int j = e ? W / 2 : 0;
+            pre_c = cov_b[(unsigned)k * (unsigned)L.Wf + (unsigned)j];
+            pre_cm = cov_b[(unsigned)(k ? H - k : 0) * (unsigned)L.Wf + (unsigned)j];
+        }
+    }
     STAMP(1);
     if (op_has_fwd(OP)) {
         // load: line r = rows (2r, 2r+1)
@@ -147,53 +186,100 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
     }
 
     // elementwise stage on S = cur
+    STAMP_LAST(20);
+    EwPtrs P = op_is_kvjp(OP) ? P_early : make_ptrs(a, b);
     EwAcc acc;
     acc_init(acc);
     for (int w = threadIdx.x; w < H * L.wc; w += blockDim.x) {
         const int i = (int)fastdiv((unsigned)w, (unsigned)L.wc, mwc), j = 1 + (w - i * L.wc);
         const cplx F = cur[i * sS + j];
-        const cplx G = ew_interior<OP>(a, L, P, i, j, F, acc);
+        double c = 1.0;
+        if (USES_COV) c = (w == (int)threadIdx.x) ? pre_ci : P.cov[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
+        const cplx G = ew_interior_c<OP>(a, L, P, i, j, F, c, acc);
         if (op_has_inv(OP)) cur[i * sS + j] = G;
         acc_renorm(acc);
     }
     acc_fold(acc);
     STAMP(6);
-    for (int k = threadIdx.x; k <= H / 2; k += blockDim.x) {
+    STAMP_LAST(21);
+    // Packed column 0 = edge column 0 + i * edge column W/2: TWO lanes per row pair (k, H - k), one per edge column, so
+    // that the two divisions and logarithms of a row run side by side, and on the LAST threads of the workgroup, whose
+    // waves have the fewest interior entries (the two loops then overlap instead of queueing up on the first wave).
+    // Lane pairs (t, t ^ 1) swap their results through DPP.
+    for (int t = tail; (t >> 1) <= H / 2; t += blockDim.x) {
+        const int k = t >> 1, e = t & 1;
         const int km = k ? H - k : 0; // (H - k) % H
-        cplx Zk = cur[k * sS], Zm = cur[km * sS];
-        ew_packed0<OP>(a, L, P, k, Zk, Zm, acc);
+        const cplx Zk = cur[k * sS], Zm = cur[km * sS];
+        // A = (Zk + conj Zm) / 2 (column 0) ; B = (Zk - conj Zm) / (2i) (column W/2)
+        cplx V = e ? make_double2(0.5 * (Zk.y + Zm.y), -0.5 * (Zk.x - Zm.x)) : make_double2(0.5 * (Zk.x + Zm.x), 0.5 * (Zk.y - Zm.y));
+        if (e == 0 || weven) {
+            const int j = e ? W / 2 : 0;
+            double c = 1.0, cm = 1.0;
+            if (USES_COV) {
+                c = (t == tail) ? pre_c : P.cov[(unsigned)k * (unsigned)L.Wf + (unsigned)j];
+                cm = (t == tail) ? pre_cm : P.cov[(unsigned)km * (unsigned)L.Wf + (unsigned)j];
+            }
+            V = ew_edge_c<OP>(a, L, P, k, j, V, c, cm, acc);
+        } else {
+            V = make_double2(0.0, 0.0);
+        }
         if (op_has_inv(OP)) {
-            cur[k * sS] = Zk;
-            if (km != k) cur[km * sS] = Zm;
+            const cplx O = make_double2(dpp_f64<0xB1, 0xf>(0.0, V.x), dpp_f64<0xB1, 0xf>(0.0, V.y)); // the other lane's
+            const cplx A = e ? O : V, B = e ? V : O;
+            // Z[k] = A + iB ; Z[H-k] = conj(A) + i conj(B)
+            if (e == 0) cur[k * sS] = make_double2(A.x - B.y, A.y + B.x);
+            else if (km != k) cur[km * sS] = make_double2(A.x + B.y, -A.y + B.x);
         }
     }
     STAMP(7);
-    if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
-        double s = acc.sum, m = acc.mn;
-        double kk[3] = {acc.k0, acc.k1, acc.k2};
-        if (op_is_kvjp(OP)) { // kernel-fused op: the three sums behind d/d(sigma, length_scale, period)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                double t = kk[i], dummy = 0.0;
-                block_sum_min(t, dummy, red);
-                kk[i] = t;
-            }
+    STAMP_LAST(22);
+    // Reduction of the log density (and the kernel-fused op's three sums): every wave leaves its sums in `red`, the
+    // barrier that separates the elementwise stage from the inverse transform anyway makes them visible, and the LAST
+    // thread (its wave has no butterflies in the stages that follow) adds them up -- off everybody else's critical path.
+    constexpr int NRED = (OP == OP_RFFT2 || OP == OP_INV_RFFT2) ? 0 : op_is_kvjp(OP) ? 5 : 2;
+    const int nw = ((int)blockDim.x + 63) >> 6, wv = (int)threadIdx.x >> 6;
+    if (NRED) {
+        const double s = wave_sum(acc.sum), m = wave_min(acc.mn);
+        double kk[3] = {0.0, 0.0, 0.0};
+        if (NRED == 5) {
+            kk[0] = wave_sum(acc.k0);
+            kk[1] = wave_sum(acc.k1);
+            kk[2] = wave_sum(acc.k2);
         }
-        block_sum_min(s, m, red);
-        if (threadIdx.x == 0) {
-            const double lp = s - 0.5 * (double)H * (double)W * 1.8378770664093454836;
-            if ((OP == OP_LPDF || op_is_lpdf_vjp(OP) || OP == OP_INV_VJP) && a.out_lpdf) a.out_lpdf[b] = lp;
-            if (op_is_kvjp(OP) && a.ksums) {
-                a.ksums[4 * b] = lp;
-                a.ksums[4 * b + 1] = kk[0];
-                a.ksums[4 * b + 2] = kk[1];
-                a.ksums[4 * b + 3] = kk[2];
+        if ((threadIdx.x & 63) == 0) {
+            red[wv] = s;
+            red[16 + wv] = m;
+            if (NRED == 5) {
+                red[32 + wv] = kk[0];
+                red[48 + wv] = kk[1];
+                red[64 + wv] = kk[2];
             }
-            if (a.min_eig) a.min_eig[b] = m;
         }
     }
     __syncthreads();
+    if (NRED && threadIdx.x == blockDim.x - 1) {
+        double s = 0.0, m = INFINITY, kk[3] = {0.0, 0.0, 0.0};
+        for (int i = 0; i < nw; ++i) {
+            s += red[i];
+            m = fmin(m, red[16 + i]);
+            if (NRED == 5) {
+                kk[0] += red[32 + i];
+                kk[1] += red[48 + i];
+                kk[2] += red[64 + i];
+            }
+        }
+        const double lp = s - 0.5 * (double)H * (double)W * 1.8378770664093454836;
+        if ((OP == OP_LPDF || op_is_lpdf_vjp(OP) || OP == OP_INV_VJP) && a.out_lpdf) a.out_lpdf[b] = lp;
+        if (op_is_kvjp(OP) && a.ksums) {
+            a.ksums[4 * b] = lp;
+            a.ksums[4 * b + 1] = kk[0];
+            a.ksums[4 * b + 2] = kk[1];
+            a.ksums[4 * b + 3] = kk[2];
+        }
+        if (a.min_eig) a.min_eig[b] = m;
+    }
     STAMP(8);
+    STAMP_LAST(23);
 
     if (op_has_inv(OP)) {
         LdsLine res = fft_h(std::true_type{}, cur, oth, NC, sS, 1);
@@ -244,8 +330,8 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
 #endif
 }
 
-template <int OP, bool TWL>
-hipError_t launch_small_v(const LatArgs& a, int cap, int sS, int nthreads, size_t lds, hipStream_t st) {
+template <int OP>
+hipError_t launch_small_t(const LatArgs& a, int cap, int sS, int nthreads, size_t lds, hipStream_t st) {
     SmallStages ss;
     auto fill = [](const LinePlan& p, StageK* k) {
         int Ns = 1;
@@ -268,18 +354,13 @@ hipError_t launch_small_v(const LatArgs& a, int cap, int sS, int nthreads, size_
     if (e != hipSuccess) return e;
     const uint64_t bit = dev < 64 ? (uint64_t)1 << dev : 0;
     if (lds > 64 * 1024 && !(attr_set.load(std::memory_order_relaxed) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_lattice_kernel<OP, TWL>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_lattice_kernel<OP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((small_lattice_kernel<OP, TWL>), dim3((unsigned)a.batch), dim3(nthreads), lds, st, a, cap, sS, ss);
+    hipLaunchKernelGGL((small_lattice_kernel<OP>), dim3((unsigned)a.batch), dim3(nthreads), lds, st, a, cap, sS, ss);
     return hipGetLastError();
-}
-template <int OP>
-hipError_t launch_small_t(const LatArgs& a, int cap, int sS, int nthreads, size_t lds, int tw_lds, hipStream_t st) {
-    return tw_lds ? launch_small_v<OP, true>(a, cap, sS, nthreads, lds, st)
-                  : launch_small_v<OP, false>(a, cap, sS, nthreads, lds, st);
 }
 
 } // namespace
@@ -292,22 +373,21 @@ bool gpt_small_fits(int H, int W, int* cap_out, int* stride_out) {
     if ((int64_t)H * sS > cap) cap = (int64_t)H * sS;
     if (cap_out) *cap_out = (int)cap;
     if (stride_out) *stride_out = sS;
-    return 512 + 2 * cap * (int64_t)sizeof(cplx) <= 160 * 1024;
+    return GPT_SMALL_HDR + 2 * cap * (int64_t)sizeof(cplx) <= 160 * 1024;
 }
 
 hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st) {
     int cap, sS;
     if (!gpt_small_fits(a.H, a.W, &cap, &sS)) return hipErrorInvalidValue;
     if (a.batch <= 0) return hipSuccess;
-    size_t lds = 512 + 2 * (size_t)cap * sizeof(cplx);
-    // the two twiddle tables ride in LDS when there is room behind the line buffers (GPT_SMALL_TW_LDS=0: A/B timing)
-    static const bool tw_off = [] { const char* e = getenv("GPT_SMALL_TW_LDS"); return e && e[0] == '0'; }();
-    const size_t tw_bytes = ((size_t)a.H + (size_t)a.W) * sizeof(cplx);
-    const int tw_lds = (!tw_off && lds + tw_bytes <= 160 * 1024) ? 1 : 0;
-    if (tw_lds) lds += tw_bytes;
+    size_t lds = GPT_SMALL_HDR + 2 * (size_t)cap * sizeof(cplx);
     int64_t work = (int64_t)a.H * a.W / 4;
     int nthreads = (int)((work + 63) / 64 * 64);
     if (nthreads < 64) nthreads = 64;
+    // short and wide (the 1-D functions: H = 1): the element loops run over W entries and are most of such a call -- a
+    // thread per entry up to 256 (n = 160, 64 chains: 12.25 us at 64 threads, 10.7 at 192; profiles/r03_k_small_threads.jsonl)
+    const int wide = a.W < 256 ? (a.W + 63) / 64 * 64 : 256;
+    if (nthreads < wide) nthreads = wide;
     if (nthreads > 1024) nthreads = 1024;
     // Many lattices per launch: throughput, not latency -- four-wave workgroups let four lattices share a CU
     // (measured at 35 x 60 with 4096 chains: 369 us at 576 threads, 166 us at 256; with 64 chains 24.5 against 26.9)
@@ -318,17 +398,17 @@ hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st) {
     }();
     if (forced >= 64 && forced <= 1024) nthreads = forced / 64 * 64;
     switch (op) {
-    case OP_RFFT2: return launch_small_t<OP_RFFT2>(a, cap, sS, nthreads, lds, tw_lds, st);
-    case OP_INV_RFFT2: return launch_small_t<OP_INV_RFFT2>(a, cap, sS, nthreads, lds, tw_lds, st);
-    case OP_GP_RFFT2: return launch_small_t<OP_GP_RFFT2>(a, cap, sS, nthreads, lds, tw_lds, st);
-    case OP_GP_INV_RFFT2: return launch_small_t<OP_GP_INV_RFFT2>(a, cap, sS, nthreads, lds, tw_lds, st);
-    case OP_LPDF: return launch_small_t<OP_LPDF>(a, cap, sS, nthreads, lds, tw_lds, st);
-    case OP_LPDF_VJP: return launch_small_t<OP_LPDF_VJP>(a, cap, sS, nthreads, lds, tw_lds, st);
-    case OP_INV_VJP: return launch_small_t<OP_INV_VJP>(a, cap, sS, nthreads, lds, tw_lds, st);
-    case OP_FWD_VJP: return launch_small_t<OP_FWD_VJP>(a, cap, sS, nthreads, lds, tw_lds, st);
-    case OP_LPDF_VJP_NOCOV: return launch_small_t<OP_LPDF_VJP_NOCOV>(a, cap, sS, nthreads, lds, tw_lds, st);
-    case OP_LPDF_KVJP: return launch_small_t<OP_LPDF_KVJP>(a, cap, sS, nthreads, lds, tw_lds, st);
-    case OP_LPDF_KVJP_EQ: return launch_small_t<OP_LPDF_KVJP_EQ>(a, cap, sS, nthreads, lds, tw_lds, st);
+    case OP_RFFT2: return launch_small_t<OP_RFFT2>(a, cap, sS, nthreads, lds, st);
+    case OP_INV_RFFT2: return launch_small_t<OP_INV_RFFT2>(a, cap, sS, nthreads, lds, st);
+    case OP_GP_RFFT2: return launch_small_t<OP_GP_RFFT2>(a, cap, sS, nthreads, lds, st);
+    case OP_GP_INV_RFFT2: return launch_small_t<OP_GP_INV_RFFT2>(a, cap, sS, nthreads, lds, st);
+    case OP_LPDF: return launch_small_t<OP_LPDF>(a, cap, sS, nthreads, lds, st);
+    case OP_LPDF_VJP: return launch_small_t<OP_LPDF_VJP>(a, cap, sS, nthreads, lds, st);
+    case OP_INV_VJP: return launch_small_t<OP_INV_VJP>(a, cap, sS, nthreads, lds, st);
+    case OP_FWD_VJP: return launch_small_t<OP_FWD_VJP>(a, cap, sS, nthreads, lds, st);
+    case OP_LPDF_VJP_NOCOV: return launch_small_t<OP_LPDF_VJP_NOCOV>(a, cap, sS, nthreads, lds, st);
+    case OP_LPDF_KVJP: return launch_small_t<OP_LPDF_KVJP>(a, cap, sS, nthreads, lds, st);
+    case OP_LPDF_KVJP_EQ: return launch_small_t<OP_LPDF_KVJP_EQ>(a, cap, sS, nthreads, lds, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -2,14 +2,14 @@
 # A/B on one box: small-lattice path with LDS-typed line buffers, inlined line transforms and twiddle tables in LDS
 # (this tree) against the library of the previous commit (gptools_amd/old/, built from a worktree of that commit).
 #   new        this tree
-#   new_twoff  this tree, GPT_SMALL_TW_LDS=0 (twiddles stay in global memory)
+
 #   old        previous commit
 set -e
 out=gpurun_out/ab_small_lds
 mkdir -p $out
 for round in 1 2; do
   timeout -k 10 120 scripts/micro/bench_small_abi > $out/new_$round.jsonl
-  GPT_SMALL_TW_LDS=0 timeout -k 10 120 scripts/micro/bench_small_abi > $out/new_twoff_$round.jsonl
+
   LD_LIBRARY_PATH=gptools_amd/old timeout -k 10 120 scripts/micro/bench_small_abi > $out/old_$round.jsonl
 done
 python - <<'PY'

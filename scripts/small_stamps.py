@@ -21,6 +21,7 @@ PHASES = ["prologue+tw", "load", "rows fwd", "split", "cols fwd", "elementwise",
 def main():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     lib.gpt_debug_small_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.gpt_debug_small_stage_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     dev = torch.device("cuda:0")
     for H, W, batch in [(1, 128, 1), (1, 100, 1), (35, 60, 1), (35, 60, 4096), (64, 64, 1)]:
         g = torch.Generator(device="cpu").manual_seed(1)
@@ -42,6 +43,15 @@ def main():
         scale = wall_us / cyc if cyc else 0.0
         rec = {"H": H, "W": W, "batch": batch, "total_us": round(wall_us, 2), "cycles": cyc,
                "phases_us": {n: round((st[i + 1] - st[i]) * scale, 2) for i, n in enumerate(PHASES)}}
+        rec["last_thread_us"] = {"interior": round((st[21] - st[20]) * scale, 2), "packed col 0": round((st[22] - st[21]) * scale, 2),
+                                 "wave sums + barrier": round((st[23] - st[22]) * scale, 2)}
+        sb = (ctypes.c_longlong * 64)()
+        assert lib.gpt_debug_small_stage_stamps(sb, 64) == 0
+        ss = list(sb)
+        # a stage's time = its stamp minus the previous stamp (phase boundary or stage), whichever is later
+        marks = sorted([(st[i], "phase") for i in range(13)] + [(ss[2 + 2 * i], int(ss[1 + 2 * i])) for i in range(int(ss[0]))])
+        rec["stages_us (radix, us)"] = [(tag, round((t - marks[i - 1][0]) * scale, 2)) for i, (t, tag) in enumerate(marks)
+                                        if tag != "phase" and i > 0]
         print(json.dumps(rec))
 
 
