@@ -6,8 +6,13 @@
 //   pass B  g_col      TC adjacent packed columns per workgroup: column FFT, elementwise stage, inverse FFT
 //   pass C  g_row_inv  LP row pairs per workgroup: merge, inverse transform, store
 // Correctness-first: the tuned code is the power-of-two path.
+#include <atomic>
+
 #include "gpt_common.h"
 #include "gpt_host.h"
+#ifndef GPT_LDS_FFT_INLINE
+#define GPT_LDS_FFT_INLINE __forceinline__ // (as in gpt_small.hip: no stack copy of the plan, no spills around a call)
+#endif
 #include "gpt_lds_fft.h"
 
 #ifndef GPT_TRACE
@@ -44,7 +49,23 @@ struct GenGeo {
     // eight columns first: tile width (bytes per workspace row) matters more to it than occupancy (301 x 200 x 64
     // lattices: 3-column tiles 204 us, 13-column tiles as before).
     int rbuf, cbuf, rthreads, cthreads;
+    // multiply-high magics (gpt_lds_fft.h) of W, NC and of the line counts of a workgroup -- LP row pairs / TC columns, or
+    // what is left for the last workgroup of a lattice
+    unsigned mW, mNC, mLP, mLPtail, mTC, mTCtail;
 };
+// Stage constants of the two line plans, made on the host (StageK, gpt_lds_fft.h)
+struct GenStages {
+    StageK s[GPT_MAX_STAGES];
+};
+GenStages make_stages(const LinePlan& p) {
+    GenStages g;
+    int Ns = 1;
+    for (int s = 0; s < p.ns && s < GPT_MAX_STAGES; ++s) {
+        g.s[s] = stage_consts(p.n, p.r[s], Ns);
+        Ns *= p.r[s];
+    }
+    return g;
+}
 
 int buf_for_line(int n) { return n <= 1024 ? 1024 : (n <= 2048 ? 2048 : G_BUF_ELEMS); }
 
@@ -69,6 +90,12 @@ GenGeo make_geo(int H, int W) {
         g.TC -= 1;
         g.TCs = g.TC | 1;
     }
+    g.mW = fastdiv_magic_hd((unsigned)W);
+    g.mNC = fastdiv_magic_hd((unsigned)g.NC);
+    g.mLP = fastdiv_magic_hd((unsigned)g.LP);
+    g.mLPtail = fastdiv_magic_hd((unsigned)(g.Hp % g.LP ? g.Hp % g.LP : g.LP));
+    g.mTC = fastdiv_magic_hd((unsigned)g.TC);
+    g.mTCtail = fastdiv_magic_hd((unsigned)(g.NC % g.TC ? g.NC % g.TC : g.TC));
     return g;
 }
 
@@ -82,30 +109,30 @@ __device__ __forceinline__ double g_in(const LatArgs& a, int64_t b, int i, int j
 }
 
 template <int IN_MODE>
-__global__ void __launch_bounds__(G_THREADS) g_row_fwd(LatArgs a, GenGeo g, cplx* __restrict__ ws) {
+__global__ void __launch_bounds__(G_THREADS) g_row_fwd(LatArgs a, GenGeo g, GenStages st, cplx* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cplx* cur = reinterpret_cast<cplx*>(smem);
-    cplx* oth = cur + g.rbuf;
+    const LdsLine cur(smem); // (LDS-typed handles, gpt_lds_fft.h)
+    const LdsLine oth = cur + g.rbuf;
     const int64_t b = blockIdx.y;
     const int H = a.H, W = a.W;
     const int r0 = blockIdx.x * g.LP;
     const int nl = min(g.LP, g.Hp - r0);
     const bool weven = (W % 2) == 0;
     for (int w = threadIdx.x; w < nl * W; w += blockDim.x) {
-        const int l = w / W, j = w - l * W, r = r0 + l;
+        const int l = (int)fastdiv((unsigned)w, (unsigned)W, g.mW), j = w - l * W, r = r0 + l;
         const double re = g_in<IN_MODE>(a, b, 2 * r, j);
         const double im = (2 * r + 1 < H) ? g_in<IN_MODE>(a, b, 2 * r + 1, j) : 0.0;
         cur[w] = make_double2(re, im);
     }
     __syncthreads();
-    const cplx* res = fft_lines_lds<false>(cur, oth, a.pw, nl, 1, W);
+    const LdsLine res = fft_lines_lds_tw<false, const cplx*>(cur, oth, a.pw, a.pw.tw, nl, 1, W, st.s, nl == g.LP ? g.mLP : g.mLPtail);
     cplx* wsb = ws + (int64_t)b * H * g.wstride;
     for (int w = threadIdx.x; w < 2 * nl * g.NC; w += blockDim.x) {
-        const int li = w / g.NC, jp = w - li * g.NC;
+        const int li = (int)fastdiv((unsigned)w, (unsigned)g.NC, g.mNC), jp = w - li * g.NC;
         const int l = li >> 1, odd = li & 1;
         const int i = 2 * (r0 + l) + odd;
         if (i >= H) continue;
-        const cplx* line = res + l * W;
+        const LdsLine line = res + l * W;
         auto rowspec = [&](int j) -> cplx {
             const cplx z = line[j];
             const cplx zc = line[j == 0 ? 0 : W - j];
@@ -124,12 +151,12 @@ __global__ void __launch_bounds__(G_THREADS) g_row_fwd(LatArgs a, GenGeo g, cplx
 }
 
 template <int OP>
-__global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, cplx* __restrict__ ws,
+__global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, GenStages st, cplx* __restrict__ ws,
                                                     double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* red = reinterpret_cast<double*>(smem); // 512 bytes
-    cplx* cur = reinterpret_cast<cplx*>(smem + 512);
-    cplx* oth = cur + g.cbuf + 16;
+    LdsLine cur(smem + 512);
+    LdsLine oth = cur + (g.cbuf + 16);
     const int64_t b = blockIdx.y;
     const int H = a.H;
     const ZLayout L = make_layout(a);
@@ -138,7 +165,7 @@ __global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, cplx* __
     const int nc = min(g.TC, g.NC - j0);
     const int sS = g.TCs;
     cplx* wsb = ws + (int64_t)b * H * g.wstride;
-    const unsigned mnc = fastdiv_magic((unsigned)nc);
+    const unsigned mnc = nc == g.TC ? g.mTC : g.mTCtail;
     GMARK(0);
     if (op_has_fwd(OP)) {
         // (unrolled: the loads of eight iterations are in flight together; one workgroup per CU has nothing else to hide
@@ -150,7 +177,7 @@ __global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, cplx* __
         }
         __syncthreads();
         GMARK(1);
-        cplx* res = fft_lines_lds<false>(cur, oth, a.ph, nc, sS, 1);
+        const LdsLine res = fft_lines_lds_tw<false, const cplx*>(cur, oth, a.ph, a.ph.tw, nc, sS, 1, st.s, mnc);
         if (res != cur) {
             oth = cur;
             cur = res;
@@ -170,7 +197,7 @@ __global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, cplx* __
     }
     if (j0 == 0) {
         for (int k = threadIdx.x; k <= H / 2; k += blockDim.x) {
-            const int km = (H - k) % H;
+            const int km = k ? H - k : 0; // (H - k) % H
             cplx Zk = cur[k * sS], Zm = cur[km * sS];
             ew_packed0<OP>(a, L, P, k, Zk, Zm, acc);
             if (op_has_inv(OP)) {
@@ -183,7 +210,7 @@ __global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, cplx* __
     __syncthreads();
     GMARK(3);
     if (op_has_inv(OP)) {
-        const cplx* res = fft_lines_lds<true>(cur, oth, a.ph, nc, sS, 1);
+        const LdsLine res = fft_lines_lds_tw<true, const cplx*>(cur, oth, a.ph, a.ph.tw, nc, sS, 1, st.s, mnc);
         GMARK(4);
         for (int w = threadIdx.x; w < H * nc; w += blockDim.x) {
             const int k = (int)fastdiv((unsigned)w, (unsigned)nc, mnc), c = w - k * nc;
@@ -203,11 +230,11 @@ __global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, cplx* __
     }
 }
 
-__global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, double alpha, int add_loc,
+__global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, GenStages st, double alpha, int add_loc,
                                                        const cplx* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cplx* cur = reinterpret_cast<cplx*>(smem);
-    cplx* oth = cur + g.rbuf;
+    const LdsLine cur(smem);
+    const LdsLine oth = cur + g.rbuf;
     const int64_t b = blockIdx.y;
     const int H = a.H, W = a.W;
     const int r0 = blockIdx.x * g.LP;
@@ -215,7 +242,7 @@ __global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, doub
     const bool weven = (W % 2) == 0;
     const cplx* wsb = ws + (int64_t)b * H * g.wstride;
     for (int w = threadIdx.x; w < nl * W; w += blockDim.x) {
-        const int l = w / W, j = w - l * W, r = r0 + l;
+        const int l = (int)fastdiv((unsigned)w, (unsigned)W, g.mW), j = w - l * W, r = r0 + l;
         auto rowspec = [&](int i, int jj) -> cplx {
             const bool mir = jj > W / 2;
             const int q = mir ? W - jj : jj;
@@ -233,10 +260,10 @@ __global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, doub
         cur[w] = make_double2(A.x - B.y, A.y + B.x);
     }
     __syncthreads();
-    const cplx* res = fft_lines_lds<true>(cur, oth, a.pw, nl, 1, W);
+    const LdsLine res = fft_lines_lds_tw<true, const cplx*>(cur, oth, a.pw, a.pw.tw, nl, 1, W, st.s, nl == g.LP ? g.mLP : g.mLPtail);
     double* ob = a.out + b * (int64_t)H * W;
     for (int w = threadIdx.x; w < nl * W; w += blockDim.x) {
-        const int l = w / W, j = w - l * W, r = r0 + l;
+        const int l = (int)fastdiv((unsigned)w, (unsigned)W, g.mW), j = w - l * W, r = r0 + l;
         const cplx v = res[w];
         for (int h = 0; h < 2; ++h) {
             const int i = 2 * r + h;
@@ -248,25 +275,39 @@ __global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, doub
     }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, device): set once per pair (one bit per device; raising
+// the cap twice is harmless, so a lost race costs one extra call), not on every launch.
+hipError_t raise_lds_cap(const void* kernel, std::atomic<uint64_t>& done, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = dev < 64 ? (uint64_t)1 << dev : 0;
+    if (done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+    return e;
+}
+
 template <int OP>
 hipError_t launch_col(const LatArgs& a, const GenGeo& g, cplx* ws, double* partials, int nblk, hipStream_t st) {
     const size_t lds = 512 + 2 * (size_t)(g.cbuf + 16) * sizeof(cplx);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g_col<OP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(512 + 2 * (size_t)(G_BUF_ELEMS + 16) * sizeof(cplx)));
+    static std::atomic<uint64_t> done{0};
+    hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&g_col<OP>), done,
+                                 (int)(512 + 2 * (size_t)(G_BUF_ELEMS + 16) * sizeof(cplx)));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(g_col<OP>, dim3(nblk, (unsigned)a.batch), dim3(g.cthreads), lds, st, a, g, ws, partials);
+    hipLaunchKernelGGL(g_col<OP>, dim3(nblk, (unsigned)a.batch), dim3(g.cthreads), lds, st, a, g, make_stages(a.ph), ws,
+                       partials);
     return hipGetLastError();
 }
 
 template <int IN_MODE> hipError_t launch_row_fwd(const LatArgs& a, const GenGeo& g, cplx* ws, hipStream_t st) {
     const size_t lds = 2 * (size_t)g.rbuf * sizeof(cplx);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g_row_fwd<IN_MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(2 * (size_t)G_BUF_ELEMS * sizeof(cplx)));
+    static std::atomic<uint64_t> done{0};
+    hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&g_row_fwd<IN_MODE>), done,
+                                 (int)(2 * (size_t)G_BUF_ELEMS * sizeof(cplx)));
     if (e != hipSuccess) return e;
     const int nb = (g.Hp + g.LP - 1) / g.LP;
-    hipLaunchKernelGGL(g_row_fwd<IN_MODE>, dim3(nb, (unsigned)a.batch), dim3(g.rthreads), lds, st, a, g, ws);
+    hipLaunchKernelGGL(g_row_fwd<IN_MODE>, dim3(nb, (unsigned)a.batch), dim3(g.rthreads), lds, st, a, g, make_stages(a.pw), ws);
     return hipGetLastError();
 }
 
@@ -322,11 +363,12 @@ hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partia
         else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
         else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
         const size_t lds = 2 * (size_t)g.rbuf * sizeof(cplx);
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g_row_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(2 * (size_t)G_BUF_ELEMS * sizeof(cplx)));
+        static std::atomic<uint64_t> done{0};
+        e = raise_lds_cap(reinterpret_cast<const void*>(&g_row_inv), done, (int)(2 * (size_t)G_BUF_ELEMS * sizeof(cplx)));
         if (e != hipSuccess) return e;
         const int nb = (g.Hp + g.LP - 1) / g.LP;
-        hipLaunchKernelGGL(g_row_inv, dim3(nb, (unsigned)a.batch), dim3(g.rthreads), lds, st, a, g, alpha, add_loc, ws);
+        hipLaunchKernelGGL(g_row_inv, dim3(nb, (unsigned)a.batch), dim3(g.rthreads), lds, st, a, g, make_stages(a.pw), alpha,
+                           add_loc, ws);
         e = hipGetLastError();
     }
     return e;
