@@ -137,6 +137,8 @@ int run_units(gpt_ctx* c, int op, const LatArgs& a, int path, int64_t chunk, cpl
 }
 
 int run_lattice(gpt_ctx* c, int op, LatArgs a) {
+    const bool armed = c->done_armed; // (one request, one launch: whatever happens below, it does not outlive this call)
+    c->done_armed = false;
     HIP_TRY(c, hipSetDevice(c->device));
     if (a.batch == 0) return GPT_OK;
     int rc;
@@ -148,7 +150,13 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
     if ((rc = make_plan(c, a.W, a.pw, path == 2)) != GPT_OK) return rc;
     if ((rc = make_plan(c, a.H, a.ph, path == 2)) != GPT_OK) return rc;
     if (path == 0) {
-        HIP_TRY(c, gpt_launch_small(op, a, c->stream));
+        unsigned long long* flag = nullptr;
+        if (armed && a.batch == 1 && c->done_dev) { // (a host entry point whose only launch this is: see gpt_ctx::done_*)
+            flag = c->done_dev;
+            c->done_published = true;
+            ++c->done_seq;
+        }
+        HIP_TRY(c, gpt_launch_small(op, a, c->stream, flag, c->done_seq));
         return GPT_OK;
     }
     if (path < 0) {

@@ -1,5 +1,6 @@
 // Host-pointer entry points of the C ABI (gpt_*_host: what the Stan user header binds): staging of the caller's
 // column-major (Stan / Eigen) or row-major host arrays, the device path, the reference's `reject`.
+#include <chrono>
 #include "gpt_ctx.h"
 #include "gpt_hostpipe.h"
 
@@ -42,6 +43,7 @@ struct Stager {
     // synchronisation of the call. Only kernels on the stream: 64 x 64 column-major 225 -> 94 (one copy each way) -> ~50 us.
     static constexpr size_t TINY_BYTES = (size_t)64 << 20; // = BOUNCE_BYTES: lattices up to 512 x 512
     bool tiny = false;
+    bool gpu_xpose = false; // a matrix of this call changes layout in a kernel (too large for the CPU to do it in passing)
     Stager(gpt_ctx* ctx, int lay, size_t need) : c(ctx), layout(lay) {
         if (hipSetDevice(c->device) != hipSuccess) {
             rc = fail(c, GPT_ERR_HIP, "hipSetDevice failed");
@@ -49,6 +51,27 @@ struct Stager {
         }
         rc = ensure(c, c->arena, c->arena_bytes, need);
         tiny = rc == GPT_OK && need <= TINY_BYTES && bounce_ready() && c->bounce_dev && need <= c->bounce_bytes;
+        c->done_armed = c->done_published = false;
+    }
+    // For the entry points whose ONE lattice launch is the last operation of the call: ask that launch to publish its
+    // completion (small calls only; run_lattice() takes it up when the one-workgroup kernel runs, finish() then spins on
+    // the flag instead of going through hipStreamSynchronize). Call right before the library call.
+    void arm() {
+        static const bool off = [] { const char* e = getenv("GPT_HOST_FLAG_SYNC"); return e && e[0] == '0'; }();
+        if (tiny && rc == GPT_OK && !off && !gpu_xpose) c->done_armed = true; // (transposes on the stream: not the last launch)
+    }
+    // true: the flag arrived; false: not within ~5 ms (a kernel that long is no small call: wait the ordinary way, which
+    // also reports a fault)
+    bool spin_done() {
+        const unsigned long long want = c->done_seq;
+        for (int round = 0; round < 5000; ++round) {
+            const auto t0 = std::chrono::steady_clock::now();
+            do {
+                for (int i = 0; i < 64; ++i)
+                    if (__atomic_load_n(c->done_host, __ATOMIC_ACQUIRE) == want) return true;
+            } while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1));
+        }
+        return false;
     }
     // the two views of the bounce area
     void* to_dev(char* host_ptr) { return c->bounce_dev + (host_ptr - c->bounce); }
@@ -105,16 +128,40 @@ struct Stager {
         void* host;
         const char* src;
         size_t bytes;
+        int R = 0, C = 0, esz = 0; // R > 0: src is an R x C row-major matrix, the caller wants it column-major
     };
+    // Matrices of a small call up to this many elements change layout on the CPU, inside the copy into / out of the
+    // bounce area that happens anyway (35 x 60 doubles: well under a microsecond each, from L1) -- a transpose kernel on
+    // either side of the lattice kernel costs two more hand-overs on the stream, and keeps the lattice launch from
+    // being the last one (arm()).
+    static constexpr int64_t CPU_XPOSE_ELEMS = 4096;
+    bool cpu_xpose(int64_t R, int64_t C) const { return tiny && is_matrix(R, C) && R * C <= CPU_XPOSE_ELEMS; }
+    // in: R x C row-major -> out: C x R row-major, elements of esz = 8 or 16 bytes
+    static void xpose_host(const void* in, void* out, int64_t R, int64_t C, int esz) {
+        if (esz == 8) {
+            const double* a = static_cast<const double*>(in);
+            double* b = static_cast<double*>(out);
+            for (int64_t c = 0; c < C; ++c)
+                for (int64_t r = 0; r < R; ++r) b[c * R + r] = a[r * C + c];
+        } else {
+            const cplx* a = static_cast<const cplx*>(in);
+            cplx* b = static_cast<cplx*>(out);
+            for (int64_t c = 0; c < C; ++c)
+                for (int64_t r = 0; r < R; ++r) b[c * R + r] = a[r * C + c];
+        }
+    }
     std::vector<Pending> pending; // downloads that sit in the bounce area until finish() has synchronised
     bool bounce_ready() {
         if (c->bounce) return true;
         void* p = nullptr;
         if (hipHostMalloc(&p, BOUNCE_BYTES, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return false;
         c->bounce = static_cast<char*>(p);
-        c->bounce_bytes = BOUNCE_BYTES;
+        c->bounce_bytes = BOUNCE_BYTES - 256; // (the tail holds the completion flag)
         void* d = nullptr;
         c->bounce_dev = hipHostGetDevicePointer(&d, p, 0) == hipSuccess ? static_cast<char*>(d) : nullptr;
+        c->done_host = reinterpret_cast<unsigned long long*>(c->bounce + c->bounce_bytes);
+        *c->done_host = 0;
+        c->done_dev = c->bounce_dev ? reinterpret_cast<unsigned long long*>(c->bounce_dev + c->bounce_bytes) : nullptr;
         return true;
     }
     char* bounce(size_t bytes) {
@@ -156,8 +203,13 @@ struct Stager {
         const size_t bytes = (size_t)R * C * esz;
         if (tiny) {
             char* b = bounce(bytes);
+            if (cpu_xpose(R, C)) { // the caller's column-major R x C = a row-major C x R
+                xpose_host(host, b, C, R, esz);
+                return to_dev(b);
+            }
             memcpy(b, host, bytes);
             if (!is_matrix(R, C)) return to_dev(b); // the kernels read it where it is
+            gpu_xpose = true;
             void* d = bump(bytes);
             xpose(to_dev(b), d, (int)C, (int)R, esz);
             return d;
@@ -177,7 +229,7 @@ struct Stager {
     // room for an R x C result of the kernels (small calls: what needs no transpose lives in the bounce area already)
     void* dev(int64_t R, int64_t C, int esz) {
         const size_t bytes = (size_t)R * C * esz;
-        if (tiny && !is_matrix(R, C)) return to_dev(bounce(bytes));
+        if (tiny && (!is_matrix(R, C) || cpu_xpose(R, C))) return to_dev(bounce(bytes));
         return bump(bytes);
     }
     // download a row-major device R x C matrix into the caller's layout
@@ -186,7 +238,12 @@ struct Stager {
         const size_t bytes = (size_t)R * C * esz;
         hipError_t e;
         if (tiny) {
-            if (is_matrix(R, C)) {
+            if (cpu_xpose(R, C)) {
+                Pending p{host, to_host(d), bytes};
+                p.R = (int)R, p.C = (int)C, p.esz = esz;
+                pending.push_back(p);
+            } else if (is_matrix(R, C)) {
+                gpu_xpose = true;
                 char* b = bounce(bytes);
                 xpose(d, to_dev(b), (int)R, (int)C, esz);
                 pending.push_back({host, b, bytes});
@@ -205,17 +262,26 @@ struct Stager {
         if (e != hipSuccess) rc = hip_fail(c, e, "download");
     }
     int finish(double* d_min_eig) {
+        const bool kernels_after = xq.n != 0; // output transposes: the lattice launch was not the last one
         xflush();
+        c->done_armed = false;
         if (rc != GPT_OK) return rc;
+        if (tiny && c->done_published && !kernels_after && spin_done()) drained = true;
+        c->done_published = false;
         double mn = INFINITY;
         if (!tiny && d_min_eig) {
             hipError_t e = hipMemcpyAsync(c->pinned, d_min_eig, sizeof(double), hipMemcpyDeviceToHost, c->stream);
             if (e != hipSuccess) return hip_fail(c, e, "min_eig read-back");
         }
-        hipError_t e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return hip_fail(c, e, "hipStreamSynchronize");
-        drained = true;
-        for (const Pending& p : pending) memcpy(p.host, p.src, p.bytes);
+        if (!drained) {
+            hipError_t e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) return hip_fail(c, e, "hipStreamSynchronize");
+            drained = true;
+        }
+        for (const Pending& p : pending) {
+            if (p.R > 0) xpose_host(p.src, p.host, p.R, p.C, p.esz);
+            else memcpy(p.host, p.src, p.bytes);
+        }
         pending.clear();
         if (d_min_eig) {
             mn = tiny ? *reinterpret_cast<const double*>(to_host(d_min_eig)) : c->pinned[0];
@@ -251,6 +317,7 @@ int gpt_gp_rfft2_host(gpt_ctx* c, int layout, const double* y, const double* loc
     double* dz = (double*)s.dev(H, W, 8);
     double* dm = (double*)s.dev(1, 1, 8);
     if (s.go()) return s.rc;
+    s.arm();
     if ((rc = gpt_gp_rfft2(c, dy, 0, dl, 0, dc, 0, H, W, 1, dim1, dz, dm))) return rc;
     s.down(z_out, dz, H, W, 8);
     return s.finish(dm);
@@ -268,6 +335,7 @@ int gpt_gp_inv_rfft2_host(gpt_ctx* c, int layout, const double* z, const double*
     double* df = (double*)s.dev(H, W, 8);
     double* dm = (double*)s.dev(1, 1, 8);
     if (s.go()) return s.rc;
+    s.arm();
     if ((rc = gpt_gp_inv_rfft2(c, dz, 0, dl, 0, dc, 0, H, W, 1, dim1, df, dm))) return rc;
     s.down(f_out, df, H, W, 8);
     return s.finish(dm);
@@ -348,6 +416,7 @@ int gpt_gp_rfft2_lpdf_host(gpt_ctx* c, int layout, const double* y, const double
     double* dgy = grad_y ? (double*)s.dev(H, W, 8) : nullptr;
     double* dgc = (grad_y && grad_cov) ? (double*)s.dev(H, Wf, 8) : nullptr;
     if (s.go()) return s.rc;
+    s.arm();
     if (grad_y) rc = gpt_gp_rfft2_lpdf_vjp(c, dy, 0, dl, 0, dc, 0, H, W, 1, dim1, dlp, dgy, dgc, dm);
     else rc = gpt_gp_rfft2_lpdf(c, dy, 0, dl, 0, dc, 0, H, W, 1, dim1, dlp, dm);
     if (rc) return rc;
@@ -369,6 +438,7 @@ int gpt_gp_inv_rfft2_vjp_host(gpt_ctx* c, int layout, const double* z, const dou
     double* dzb = (double*)s.dev(H, W, 8);
     double* dcb = covbar ? (double*)s.dev(H, Wf, 8) : nullptr;
     if (s.go()) return s.rc;
+    s.arm();
     if ((rc = gpt_gp_inv_rfft2_vjp(c, dz, 0, dc, 0, dfb, 0, H, W, 1, dim1, dzb, dcb))) return rc;
     s.down(zbar, dzb, H, W, 8);
     if (covbar) s.down(covbar, dcb, H, Wf, 8);
@@ -388,6 +458,7 @@ int gpt_gp_rfft2_vjp_host(gpt_ctx* c, int layout, const double* y, const double*
     double* dyb = (double*)s.dev(H, W, 8);
     double* dcb = covbar ? (double*)s.dev(H, Wf, 8) : nullptr;
     if (s.go()) return s.rc;
+    s.arm();
     if ((rc = gpt_gp_rfft2_vjp(c, dy, 0, dl, 0, dc, 0, dzb, 0, H, W, 1, dim1, dyb, dcb))) return rc;
     s.down(ybar, dyb, H, W, 8);
     if (covbar) s.down(covbar, dcb, H, Wf, 8);
@@ -403,6 +474,7 @@ int gpt_rfft2_host(gpt_ctx* c, int layout, const double* y, int64_t H, int64_t W
     const double* dy = (const double*)s.up(y, H, W, 8);
     double* dout = (double*)s.dev(H, Wf, 16);
     if (s.go()) return s.rc;
+    s.arm();
     if ((rc = gpt_rfft2(c, dy, H, W, 1, dout))) return rc;
     s.down(out_complex, dout, H, Wf, 16);
     return s.finish(nullptr);
@@ -416,6 +488,7 @@ int gpt_inv_rfft2_host(gpt_ctx* c, int layout, const double* z_complex, int64_t 
     const double* dz = (const double*)s.up(z_complex, H, Wf, 16);
     double* dout = (double*)s.dev(H, W, 8);
     if (s.go()) return s.rc;
+    s.arm();
     if ((rc = gpt_inv_rfft2(c, dz, H, W, 1, dout))) return rc;
     s.down(out, dout, H, W, 8);
     return s.finish(nullptr);

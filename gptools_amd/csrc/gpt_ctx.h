@@ -50,6 +50,16 @@ struct gpt_ctx {
     char* bounce = nullptr;     // host view
     char* bounce_dev = nullptr; // device view of the same memory
     size_t bounce_bytes = 0;
+    // Completion of a small host call, published by its one kernel (gpt_small.hip) instead of waited for through the
+    // runtime: a sequence number in the last 256 bytes of the bounce allocation, stored by the kernel with a system-scope
+    // release after its last result, spun on by the host (launch + hipStreamSynchronize of an empty kernel: 11.1 us on
+    // this box; kernel-stored flag + spin: 6.0 -- profiles/r03_m_sync_latency.txt). done_armed: the entry point asks for
+    // it (only those whose one launch is the last thing on the stream); done_published: run_lattice() did hand the flag
+    // to a one-lattice small launch.
+    unsigned long long* done_host = nullptr;
+    unsigned long long* done_dev = nullptr;
+    unsigned long long done_seq = 0;
+    bool done_armed = false, done_published = false;
 };
 
 // Built-in scratch of the allocation-free entry point (gpt_api_noalloc.hip): bytes per GPU

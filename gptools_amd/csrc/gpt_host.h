@@ -5,7 +5,9 @@
 
 // --- small-lattice path (gpt_small.hip)
 bool gpt_small_fits(int H, int W, int* cap_out, int* stride_out);
-hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st);
+// done_flag (device view of host-mapped memory) != null and a.batch == 1: the kernel stores done_seq there after its last result
+hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st, unsigned long long* done_flag = nullptr,
+                            unsigned long long done_seq = 0);
 
 // --- large power-of-two path (gpt_pow2.hip)
 // Workspace: packed spectrum, (H * (W/2 + GPT_WS_PAD)) complex per lattice processed concurrently.

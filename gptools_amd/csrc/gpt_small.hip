@@ -71,6 +71,9 @@ struct SmallStages {
     StageK w[GPT_MAX_STAGES], h[GPT_MAX_STAGES];
     unsigned mLw, mLh;
     unsigned mW, mNC, mwc; // magics of the element loops: W, NC = 1 + (W - 1) / 2, max((W - 1) / 2, 1)
+    // one-lattice launches of the host-pointer entry points: where to publish completion (gpt_ctx::done_*), or null
+    unsigned long long* done_flag;
+    unsigned long long done_seq;
 };
 
 template <int OP>
@@ -119,12 +122,17 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
     // registers, instead of a memory round trip in the middle of the kernel
     constexpr bool USES_COV = OP != OP_RFFT2 && OP != OP_INV_RFFT2 && !op_is_kvjp(OP);
     const int tail = (int)blockDim.x - 1 - (int)threadIdx.x; // work item of the packed-column loop: (row k, edge column)
-    double pre_ci = 1.0, pre_c = 1.0, pre_cm = 1.0;
+    double pre_ci = 1.0, pre_ci1 = 1.0, pre_c = 1.0, pre_cm = 1.0;
     if (USES_COV) {
         const double* cov_b = a.cov + b * a.cov_bs;
         if ((int)threadIdx.x < H * L.wc) {
             const int i = (int)fastdiv(threadIdx.x, (unsigned)L.wc, mwc), j = 1 + ((int)threadIdx.x - i * L.wc);
             pre_ci = cov_b[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
+        }
+        if ((int)(threadIdx.x + blockDim.x) < H * L.wc) { // ... and of its second
+            const unsigned w1 = threadIdx.x + blockDim.x;
+            const int i = (int)fastdiv(w1, (unsigned)L.wc, mwc), j = 1 + ((int)w1 - i * L.wc);
+            pre_ci1 = cov_b[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
         }
         const int k = tail >> 1, e = tail & 1;
         if (k <= H / 2 && (e == 0 || weven)) {
@@ -136,11 +144,20 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
     STAMP(1);
     if (op_has_fwd(OP)) {
         // load: line r = rows (2r, 2r+1)
-        for (int w = threadIdx.x; w < Hp * W; w += blockDim.x) {
+        // (two entries per trip, all their loads asked for before the first is used: one memory round trip for a
+        // 35 x 60 lattice on 576 threads instead of two -- a round trip is 0.5 us in HBM and 2.5 us when the host-pointer
+        // entry points let the kernel read the caller's arrays in pinned host memory)
+        for (int w = threadIdx.x; w < Hp * W; w += 2 * blockDim.x) {
+            const int w1 = w + (int)blockDim.x;
+            const bool two = w1 < Hp * W;
             const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
+            const int r1 = two ? (int)fastdiv((unsigned)w1, (unsigned)W, mW) : r, j1 = two ? w1 - r1 * W : j;
             const double re = in_transform<OP>(a, b, 2 * r, j);
             const double im = (2 * r + 1 < H) ? in_transform<OP>(a, b, 2 * r + 1, j) : 0.0;
+            const double re1 = in_transform<OP>(a, b, 2 * r1, j1);
+            const double im1 = (2 * r1 + 1 < H) ? in_transform<OP>(a, b, 2 * r1 + 1, j1) : 0.0;
             cur[w] = make_double2(re, im);
+            if (two) cur[w1] = make_double2(re1, im1);
         }
         __syncthreads();
         STAMP(2);
@@ -194,7 +211,10 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         const int i = (int)fastdiv((unsigned)w, (unsigned)L.wc, mwc), j = 1 + (w - i * L.wc);
         const cplx F = cur[i * sS + j];
         double c = 1.0;
-        if (USES_COV) c = (w == (int)threadIdx.x) ? pre_ci : P.cov[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
+        if (USES_COV)
+            c = (w == (int)threadIdx.x) ? pre_ci
+                                        : (w == (int)(threadIdx.x + blockDim.x)) ? pre_ci1
+                                                                                 : P.cov[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
         const cplx G = ew_interior_c<OP>(a, L, P, i, j, F, c, acc);
         if (op_has_inv(OP)) cur[i * sS + j] = G;
         acc_renorm(acc);
@@ -323,6 +343,12 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
             if (2 * r + 1 < H) o[(int64_t)(2 * r + 1) * W + j] = out_transform<OP>(a, b, 2 * r + 1, j, v.y);
         }
     }
+    if (ss.done_flag) { // (uniform; one workgroup: batch == 1)
+        // every thread's results are out at system scope, then ONE release store of the sequence number the host spins on
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(ss.done_flag, ss.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     STAMP(12);
     STAMP(17);
 #ifdef GPT_SMALL_STAMPS
@@ -331,8 +357,11 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
 }
 
 template <int OP>
-hipError_t launch_small_t(const LatArgs& a, int cap, int sS, int nthreads, size_t lds, hipStream_t st) {
+hipError_t launch_small_t(const LatArgs& a, int cap, int sS, int nthreads, size_t lds, hipStream_t st,
+                          unsigned long long* done_flag, unsigned long long done_seq) {
     SmallStages ss;
+    ss.done_flag = a.batch == 1 ? done_flag : nullptr;
+    ss.done_seq = done_seq;
     auto fill = [](const LinePlan& p, StageK* k) {
         int Ns = 1;
         for (int s = 0; s < p.ns && s < GPT_MAX_STAGES; ++s) {
@@ -376,7 +405,8 @@ bool gpt_small_fits(int H, int W, int* cap_out, int* stride_out) {
     return GPT_SMALL_HDR + 2 * cap * (int64_t)sizeof(cplx) <= 160 * 1024;
 }
 
-hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st) {
+hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st, unsigned long long* done_flag,
+                            unsigned long long done_seq) {
     int cap, sS;
     if (!gpt_small_fits(a.H, a.W, &cap, &sS)) return hipErrorInvalidValue;
     if (a.batch <= 0) return hipSuccess;
@@ -398,17 +428,17 @@ hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st) {
     }();
     if (forced >= 64 && forced <= 1024) nthreads = forced / 64 * 64;
     switch (op) {
-    case OP_RFFT2: return launch_small_t<OP_RFFT2>(a, cap, sS, nthreads, lds, st);
-    case OP_INV_RFFT2: return launch_small_t<OP_INV_RFFT2>(a, cap, sS, nthreads, lds, st);
-    case OP_GP_RFFT2: return launch_small_t<OP_GP_RFFT2>(a, cap, sS, nthreads, lds, st);
-    case OP_GP_INV_RFFT2: return launch_small_t<OP_GP_INV_RFFT2>(a, cap, sS, nthreads, lds, st);
-    case OP_LPDF: return launch_small_t<OP_LPDF>(a, cap, sS, nthreads, lds, st);
-    case OP_LPDF_VJP: return launch_small_t<OP_LPDF_VJP>(a, cap, sS, nthreads, lds, st);
-    case OP_INV_VJP: return launch_small_t<OP_INV_VJP>(a, cap, sS, nthreads, lds, st);
-    case OP_FWD_VJP: return launch_small_t<OP_FWD_VJP>(a, cap, sS, nthreads, lds, st);
-    case OP_LPDF_VJP_NOCOV: return launch_small_t<OP_LPDF_VJP_NOCOV>(a, cap, sS, nthreads, lds, st);
-    case OP_LPDF_KVJP: return launch_small_t<OP_LPDF_KVJP>(a, cap, sS, nthreads, lds, st);
-    case OP_LPDF_KVJP_EQ: return launch_small_t<OP_LPDF_KVJP_EQ>(a, cap, sS, nthreads, lds, st);
+    case OP_RFFT2: return launch_small_t<OP_RFFT2>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);
+    case OP_INV_RFFT2: return launch_small_t<OP_INV_RFFT2>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);
+    case OP_GP_RFFT2: return launch_small_t<OP_GP_RFFT2>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);
+    case OP_GP_INV_RFFT2: return launch_small_t<OP_GP_INV_RFFT2>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);
+    case OP_LPDF: return launch_small_t<OP_LPDF>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);
+    case OP_LPDF_VJP: return launch_small_t<OP_LPDF_VJP>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);
+    case OP_INV_VJP: return launch_small_t<OP_INV_VJP>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);
+    case OP_FWD_VJP: return launch_small_t<OP_FWD_VJP>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);
+    case OP_LPDF_VJP_NOCOV: return launch_small_t<OP_LPDF_VJP_NOCOV>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);
+    case OP_LPDF_KVJP: return launch_small_t<OP_LPDF_KVJP>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);
+    case OP_LPDF_KVJP_EQ: return launch_small_t<OP_LPDF_KVJP_EQ>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);
     default: return hipErrorInvalidValue;
     }
 }

@@ -81,22 +81,23 @@ int main() {
             CK(hipGraphDestroy(graph));
         }
         // the Stan-side call: one chain, host pointers, column-major, synchronous
-        double us_host = -1.0;
+        // (and row-major: what a C or NumPy caller passes; a 1-D call has no layout)
+        double us_host = -1.0, us_host_rm = -1.0;
         if (c.batch == 1) {
-            double mn = 0.0;
-            auto host_call = [&] {
-                const int rc = gpt_gp_rfft2_lpdf_host(ctx, GPT_COL_MAJOR, y.data(), loc.data(), cov.data(), c.H, c.W, dim1, lp.data(), gy.data(), gc.data());
-                if (rc != GPT_OK) { printf("host call -> %d: %s\n", rc, gpt_last_error(ctx)); exit(1); }
-            };
-            (void)mn;
-            for (int i = 0; i < 20; ++i) host_call();
-            t0 = now();
-            for (int i = 0; i < 500; ++i) host_call();
-            us_host = 1e6 * (now() - t0) / 500;
+            for (int layout : {GPT_COL_MAJOR, GPT_ROW_MAJOR}) {
+                auto host_call = [&] {
+                    const int rc = gpt_gp_rfft2_lpdf_host(ctx, layout, y.data(), loc.data(), cov.data(), c.H, c.W, dim1, lp.data(), gy.data(), gc.data());
+                    if (rc != GPT_OK) { printf("host call -> %d: %s\n", rc, gpt_last_error(ctx)); exit(1); }
+                };
+                for (int i = 0; i < 20; ++i) host_call();
+                t0 = now();
+                for (int i = 0; i < 500; ++i) host_call();
+                (layout == GPT_COL_MAJOR ? us_host : us_host_rm) = 1e6 * (now() - t0) / 500;
+            }
         }
         printf("{\"case\": \"%s\", \"us_per_call_device_ptr\": %.2f, \"evals_per_s_device_ptr\": %.0f, \"us_per_graph_replay_noalloc\": %.2f, "
-               "\"us_per_call_host_ptr_col_major\": %.2f}\n",
-               c.label, us_dev, c.batch / (1e-6 * us_dev), us_graph, us_host);
+               "\"us_per_call_host_ptr_col_major\": %.2f, \"us_per_call_host_ptr_row_major\": %.2f}\n",
+               c.label, us_dev, c.batch / (1e-6 * us_dev), us_graph, us_host, us_host_rm);
         fflush(stdout);
         CK(hipFree(dy)); CK(hipFree(dl)); CK(hipFree(dc)); CK(hipFree(dlp)); CK(hipFree(dgy)); CK(hipFree(dgc)); CK(hipFree(dmn));
     }
