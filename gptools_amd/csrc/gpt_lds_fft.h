@@ -1,8 +1,6 @@
 // Mixed-radix Stockham line FFT on lines that live in LDS (any length: arbitrary prime factors). Shared by
 // the small-lattice kernel and the generic three-pass kernels.
 #pragma once
-#include <type_traits>
-
 #include "gpt_common.h"
 #include "gpt_bfly.h"
 
@@ -100,19 +98,9 @@ __host__ __device__ __forceinline__ StageK stage_consts(int N, int R, int Ns) {
     k.mNs = fastdiv_magic_hd((unsigned)Ns);
     return k;
 }
-// Where a stage reads its inputs and leaves its outputs: element e of line l of a tile in LDS (LdsAt), or whatever the
-// caller puts in its place for the FIRST stage's loads and the LAST stage's stores (fft_lines_lds_fused: the small-lattice
-// kernel reads the lattice from global memory / separates row pairs / merges them inside the first stage, and stores the
-// result from inside the last one -- each a pass over LDS and a barrier less).
-struct LdsAt {
-    LdsLine base;
-    int es, ls;
-    __device__ __forceinline__ cplx load(int l, int e) const { return base[l * ls + e * es]; }
-    __device__ __forceinline__ void store(int l, int e, const cplx& v) const { base[l * ls + e * es] = v; }
-};
-template <int R, bool INVERSE, typename TWP, typename LD, typename ST>
-__device__ __forceinline__ void stage_lds(const LD& ld, const ST& st, TWP tw, const StageK& sk, int nlines, unsigned mL,
-                                          bool across) {
+template <int R, bool INVERSE, typename TWP>
+__device__ __forceinline__ void stage_lds(const LdsLine src, const LdsLine dst, TWP tw, const StageK& sk, int nlines,
+                                          unsigned mL, int es, int ls) {
     // (M = N / R, tstep = N / (Ns R) and the division magics of M, Ns, nlines arrive ready-made: see StageK)
     const int Ns = sk.Ns, M = sk.M, tstep = sk.tstep, total = nlines * M;
     const unsigned mM = sk.mM, mNs = sk.mNs;
@@ -120,7 +108,8 @@ __device__ __forceinline__ void stage_lds(const LD& ld, const ST& st, TWP tw, co
     // Work items are numbered so that neighbouring lanes touch neighbouring LDS addresses: along a line when its
     // elements are contiguous (es == 1: row tiles), across the lines when the lines are interleaved (ls == 1: column
     // tiles, element stride = tile width -- numbered along the line, every access of a wave was a 2- to 4-way bank
-    // conflict): across = (ls == 1 && es > 1).
+    // conflict).
+    const bool across = (ls == 1 && es > 1);
 #pragma unroll 1
     for (int w = threadIdx.x; w < total; w += blockDim.x) {
         int line, j;
@@ -132,9 +121,10 @@ __device__ __forceinline__ void stage_lds(const LD& ld, const ST& st, TWP tw, co
             j = w - line * M;
         }
         const int hi = (int)fastdiv((unsigned)j, (unsigned)Ns, mNs), k = j - hi * Ns;
-        cplx x[R], y[R];
+        const LdsLine in = src + (line * ls + j * es);
+        cplx x[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) x[q] = ld.load(line, j + q * M);
+        for (int q = 0; q < R; ++q) x[q] = in[q * M * es];
         if (Ns > 1) {
             const int e = k * tstep; // q e < N for q < R
             // (computing w^e with sincospi instead of loading it, for stages with only a butterfly or two per thread, was
@@ -146,25 +136,27 @@ __device__ __forceinline__ void stage_lds(const LD& ld, const ST& st, TWP tw, co
                 x[q] = cmul(x[q], t);
             }
         }
+        const LdsLine out = dst + (line * ls + (hi * Ns * R + k) * es);
+        const int os = Ns * es;
         if constexpr (R == 2) {
-            y[0] = cadd(x[0], x[1]);
-            y[1] = csub(x[0], x[1]);
+            out[0] = cadd(x[0], x[1]);
+            out[os] = csub(x[0], x[1]);
         } else if constexpr (R == 4) {
             const cplx a = cadd(x[0], x[2]), b = csub(x[0], x[2]), c = cadd(x[1], x[3]), d0 = csub(x[1], x[3]);
             const cplx d = INVERSE ? make_double2(-d0.y, d0.x) : make_double2(d0.y, -d0.x); // -+ i (x1 - x3)
-            y[0] = cadd(a, c);
-            y[1] = cadd(b, d);
-            y[2] = csub(a, c);
-            y[3] = csub(b, d);
+            out[0] = cadd(a, c);
+            out[os] = cadd(b, d);
+            out[2 * os] = csub(a, c);
+            out[3 * os] = csub(b, d);
         } else if constexpr (R == 3) {
             constexpr double s3 = 0.86602540378443864676; // sin(2 pi / 3)
             const cplx t = cadd(x[1], x[2]), u = csub(x[1], x[2]);
             const cplx m1 = make_double2(fma(-0.5, t.x, x[0].x), fma(-0.5, t.y, x[0].y));
             // -+ i s3 u
             const cplx m2 = INVERSE ? make_double2(-s3 * u.y, s3 * u.x) : make_double2(s3 * u.y, -s3 * u.x);
-            y[0] = cadd(x[0], t);
-            y[1] = cadd(m1, m2);
-            y[2] = csub(m1, m2);
+            out[0] = cadd(x[0], t);
+            out[os] = cadd(m1, m2);
+            out[2 * os] = csub(m1, m2);
         } else if constexpr (R == 5) {
             constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410; // cos(2 pi / 5), cos(4 pi / 5)
             constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917; // sin(2 pi / 5), sin(4 pi / 5)
@@ -176,15 +168,15 @@ __device__ __forceinline__ void stage_lds(const LD& ld, const ST& st, TWP tw, co
             // forward: X1 = a1 - i b1, X4 = a1 + i b1, X2 = a2 - i b2, X3 = a2 + i b2 (inverse: the signs swap)
             const cplx ib1 = INVERSE ? make_double2(-b1.y, b1.x) : make_double2(b1.y, -b1.x);
             const cplx ib2 = INVERSE ? make_double2(-b2.y, b2.x) : make_double2(b2.y, -b2.x);
-            y[0] = make_double2(x[0].x + t1.x + t2.x, x[0].y + t1.y + t2.y);
-            y[1] = cadd(a1, ib1);
-            y[2] = cadd(a2, ib2);
-            y[3] = csub(a2, ib2);
-            y[4] = csub(a1, ib1);
+            out[0] = make_double2(x[0].x + t1.x + t2.x, x[0].y + t1.y + t2.y);
+            out[os] = cadd(a1, ib1);
+            out[2 * os] = cadd(a2, ib2);
+            out[3 * os] = csub(a2, ib2);
+            out[4 * os] = csub(a1, ib1);
         } else if constexpr (R == 8 || R == 16) { // register butterflies of the power-of-two kernels: one LDS pass for 3 / 4 bits
             pow2::Bfly<R, INVERSE>::run(x);
 #pragma unroll
-            for (int p = 0; p < R; ++p) y[p] = x[p];
+            for (int p = 0; p < R; ++p) out[p * os] = x[p];
         } else {
             // odd prime radix (7, 11, 13), inputs paired about the middle: with s_q = x_q + x_{R-q}, d_q = x_q - x_{R-q},
             //   X_p = a_p -+ i b_p,  X_{R-p} = a_p +- i b_p,  a_p = x_0 + sum_q s_q cos(2 pi p q / R),  b_p = sum_q d_q sin(...)
@@ -199,7 +191,7 @@ __device__ __forceinline__ void stage_lds(const LD& ld, const ST& st, TWP tw, co
             cplx o0 = x[0];
 #pragma unroll
             for (int q = 0; q < h; ++q) o0 = cadd(o0, sq[q]);
-            y[0] = o0;
+            out[0] = o0;
 #pragma unroll
             for (int p = 1; p <= h; ++p) {
                 cplx av = x[0], bv = make_double2(0.0, 0.0);
@@ -213,13 +205,10 @@ __device__ __forceinline__ void stage_lds(const LD& ld, const ST& st, TWP tw, co
                 }
                 // forward: X_p = a - i b, X_{R-p} = a + i b (inverse: the other way round)
                 const cplx lo = make_double2(av.x + bv.y, av.y - bv.x), hi2 = make_double2(av.x - bv.y, av.y + bv.x);
-                y[p] = INVERSE ? hi2 : lo;
-                y[R - p] = INVERSE ? lo : hi2;
+                out[p * os] = INVERSE ? hi2 : lo;
+                out[(R - p) * os] = INVERSE ? lo : hi2;
             }
         }
-        const int e0 = hi * Ns * R + k;
-#pragma unroll
-        for (int p = 0; p < R; ++p) st.store(line, e0 + p * Ns, y[p]);
     }
 }
 
@@ -229,24 +218,21 @@ __device__ __forceinline__ void stage_lds(const LD& ld, const ST& st, TWP tw, co
 // Returns the buffer that holds the result.
 //
 // stage_lds_any: one stage with ready-made constants; false: the radix has no butterfly of its own (generic loop of the caller).
-template <bool INVERSE, typename TWP, typename LD, typename ST>
-__device__ __forceinline__ bool stage_lds_any(const LD& ld, const ST& st, TWP ptw, const StageK& sk, int nlines, unsigned mL,
-                                              bool across) {
+template <bool INVERSE, typename TWP>
+__device__ __forceinline__ bool stage_lds_any(LdsLine src, LdsLine dst, TWP ptw, const StageK& sk, int nlines, unsigned mL,
+                                              int es, int ls) {
     switch (sk.R) {
-    case 2: stage_lds<2, INVERSE, TWP>(ld, st, ptw, sk, nlines, mL, across); return true;
-    case 3: stage_lds<3, INVERSE, TWP>(ld, st, ptw, sk, nlines, mL, across); return true;
-    case 4: stage_lds<4, INVERSE, TWP>(ld, st, ptw, sk, nlines, mL, across); return true;
-    case 5: stage_lds<5, INVERSE, TWP>(ld, st, ptw, sk, nlines, mL, across); return true;
-    case 7: stage_lds<7, INVERSE, TWP>(ld, st, ptw, sk, nlines, mL, across); return true;
-    case 8: stage_lds<8, INVERSE, TWP>(ld, st, ptw, sk, nlines, mL, across); return true;
-    case 16: stage_lds<16, INVERSE, TWP>(ld, st, ptw, sk, nlines, mL, across); return true;
-    case 11: stage_lds<11, INVERSE, TWP>(ld, st, ptw, sk, nlines, mL, across); return true;
-    case 13: stage_lds<13, INVERSE, TWP>(ld, st, ptw, sk, nlines, mL, across); return true;
+    case 2: stage_lds<2, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 3: stage_lds<3, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 4: stage_lds<4, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 5: stage_lds<5, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 7: stage_lds<7, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 8: stage_lds<8, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 16: stage_lds<16, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 11: stage_lds<11, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
+    case 13: stage_lds<13, INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls); return true;
     default: return false;
     }
-}
-__host__ __device__ __forceinline__ bool radix_has_butterfly(int R) {
-    return R == 2 || R == 3 || R == 4 || R == 5 || R == 7 || R == 8 || R == 11 || R == 13 || R == 16;
 }
 
 // `stages`: null (constants worked out here, stage by stage) or the host-made table of the plan's p.ns stages.
@@ -255,12 +241,11 @@ __device__ GPT_LDS_FFT_INLINE LdsLine fft_lines_lds_tw(LdsLine src, LdsLine dst,
                                                        int ls, const StageK* stages = nullptr, unsigned mL_ready = 0) {
     const int N = p.n;
     const unsigned mL = stages ? mL_ready : fastdiv_magic((unsigned)nlines);
-    const bool across = (ls == 1 && es > 1);
     int Ns = 1;
     for (int s = 0; s < p.ns; ++s) {
         const StageK sk = stages ? stages[s] : stage_consts(N, p.r[s], Ns);
         const int R = sk.R;
-        const bool done = stage_lds_any<INVERSE, TWP>(LdsAt{src, es, ls}, LdsAt{dst, es, ls}, ptw, sk, nlines, mL, across);
+        const bool done = stage_lds_any<INVERSE, TWP>(src, dst, ptw, sk, nlines, mL, es, ls);
         if (done) {
             __syncthreads();
             GPT_STAGE_STAMP(R);
@@ -272,6 +257,7 @@ __device__ GPT_LDS_FFT_INLINE LdsLine fft_lines_lds_tw(LdsLine src, LdsLine dst,
         }
         const int M = sk.M, tstep = sk.tstep, total = nlines * N;
         const unsigned mN = fastdiv_magic((unsigned)N), mNs = sk.mNs, mR = fastdiv_magic((unsigned)R);
+        const bool across = (ls == 1 && es > 1); // (as in stage_lds)
         for (int w = threadIdx.x; w < total; w += blockDim.x) {
             int line, o;
             if (across) {
@@ -308,41 +294,6 @@ __device__ GPT_LDS_FFT_INLINE LdsLine fft_lines_lds_tw(LdsLine src, LdsLine dst,
         src = dst;
         dst = tmp;
         Ns *= R;
-    }
-    return src;
-}
-
-// The same with the first stage's loads and / or the last stage's stores in the caller's hands (NoFuse: not this end).
-// Needs host-made stage constants, at least one stage, and a butterfly for every radix (radix_has_butterfly: the caller
-// checks, and takes the plain loop otherwise). The first stage writes `dst` (whatever it reads), the stages then swing
-// between the two buffers as usual; returns the buffer that holds the result -- of the last but one stage when the
-// last one stores elsewhere.
-struct NoFuse {};
-template <bool INVERSE, typename TWP, typename LD0, typename STL>
-__device__ __forceinline__ LdsLine fft_lines_lds_fused(LdsLine src, LdsLine dst, int ns, TWP ptw, int nlines, int es, int ls,
-                                                       const StageK* stages, unsigned mL, const LD0& ld0, const STL& stl) {
-    constexpr bool F0 = !std::is_same<LD0, NoFuse>::value, FL = !std::is_same<STL, NoFuse>::value;
-    const bool across = (ls == 1 && es > 1);
-    for (int s = 0; s < ns; ++s) {
-        const StageK sk = stages[s];
-        const bool first = F0 && s == 0, last = FL && s == ns - 1;
-        const LdsAt in{src, es, ls}, out{dst, es, ls};
-        if constexpr (F0 && FL) {
-            if (first && last) stage_lds_any<INVERSE, TWP>(ld0, stl, ptw, sk, nlines, mL, across);
-        }
-        if constexpr (F0) {
-            if (first && !last) stage_lds_any<INVERSE, TWP>(ld0, out, ptw, sk, nlines, mL, across);
-        }
-        if constexpr (FL) {
-            if (last && !first) stage_lds_any<INVERSE, TWP>(in, stl, ptw, sk, nlines, mL, across);
-        }
-        if (!first && !last) stage_lds_any<INVERSE, TWP>(in, out, ptw, sk, nlines, mL, across);
-        if (last) return src;
-        __syncthreads();
-        GPT_STAGE_STAMP(sk.R);
-        const LdsLine tmp = src;
-        src = dst;
-        dst = tmp;
     }
     return src;
 }

@@ -74,9 +74,6 @@ struct SmallStages {
     // one-lattice launches of the host-pointer entry points: where to publish completion (gpt_ctx::done_*), or null
     unsigned long long* done_flag;
     unsigned long long done_seq;
-    // 1: the plan has at least one stage and a butterfly for every radix -- its first / last stage may read / write
-    // somewhere other than LDS (fft_lines_lds_fused)
-    int fuse_w, fuse_h;
 };
 
 template <int OP>
@@ -145,26 +142,35 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         }
     }
     STAMP(1);
-    // The first stage of a transform reads its inputs wherever they are -- the lattice in global memory, the row pairs that
-    // have to be separated -- and the last stage of the inverse stores the result: no pass over LDS and no barrier just
-    // to move data (fft_lines_lds_fused, gpt_lds_fft.h). Plans with a radix that has no butterfly of its own, or with
-    // no stage at all (H = 1: the 1-D functions have no column transform), take the separate loops (ss.fuse_w, ss.fuse_h).
-    struct RowLoad { // element j of line r = rows (2r, 2r + 1) of the input, as one complex number
-        const LatArgs& a;
-        int64_t b;
-        int H;
-        __device__ __forceinline__ cplx load(int r, int j) const {
+    if (op_has_fwd(OP)) {
+        // load: line r = rows (2r, 2r+1)
+        // (two entries per trip, all their loads asked for before the first is used: one memory round trip for a
+        // 35 x 60 lattice on 576 threads instead of two -- a round trip is 0.5 us in HBM and 2.5 us when the host-pointer
+        // entry points let the kernel read the caller's arrays in pinned host memory)
+        for (int w = threadIdx.x; w < Hp * W; w += 2 * blockDim.x) {
+            const int w1 = w + (int)blockDim.x;
+            const bool two = w1 < Hp * W;
+            const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
+            const int r1 = two ? (int)fastdiv((unsigned)w1, (unsigned)W, mW) : r, j1 = two ? w1 - r1 * W : j;
             const double re = in_transform<OP>(a, b, 2 * r, j);
             const double im = (2 * r + 1 < H) ? in_transform<OP>(a, b, 2 * r + 1, j) : 0.0;
-            return make_double2(re, im);
+            const double re1 = in_transform<OP>(a, b, 2 * r1, j1);
+            const double im1 = (2 * r1 + 1 < H) ? in_transform<OP>(a, b, 2 * r1 + 1, j1) : 0.0;
+            cur[w] = make_double2(re, im);
+            if (two) cur[w1] = make_double2(re1, im1);
         }
-    };
-    struct SplitLoad { // row i of packed column jp, out of the transformed row pairs (lines of W points at `rows`)
-        LdsLine rows;
-        int W;
-        bool weven;
-        __device__ __forceinline__ cplx load(int jp, int i) const {
-            const LdsLine line = rows + (i >> 1) * W;
+        __syncthreads();
+        STAMP(2);
+        LdsLine res = fft_w(std::false_type{}, cur, oth, Hp, 1, W);
+        if (res != cur) {
+            oth = cur;
+            cur = res;
+        }
+        STAMP(3);
+        // split row pairs -> packed spectrum S[i * sS + jp] in `oth`
+        for (int w = threadIdx.x; w < H * NC; w += blockDim.x) {
+            const int i = (int)fastdiv((unsigned)w, (unsigned)NC, mNC), jp = w - i * NC;
+            const LdsLine line = cur + (i >> 1) * W;
             auto rowspec = [&](int j) -> cplx {
                 const cplx z = line[j];
                 const cplx zc = line[j == 0 ? 0 : W - j];
@@ -172,84 +178,28 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
                 if ((i & 1) == 0) return make_double2(0.5 * (z.x + zc.x), 0.5 * (z.y - zc.y));
                 return make_double2(0.5 * (z.y + zc.y), -0.5 * (z.x - zc.x));
             };
-            if (jp != 0) return rowspec(jp);
-            return make_double2(rowspec(0).x, weven ? rowspec(W / 2).x : 0.0);
+            cplx v;
+            if (jp == 0) {
+                v.x = rowspec(0).x;
+                v.y = weven ? rowspec(W / 2).x : 0.0;
+            } else {
+                v = rowspec(jp);
+            }
+            oth[i * sS + jp] = v;
         }
-    };
-    if (op_has_fwd(OP)) {
-        if (ss.fuse_w) {
-            cur = fft_lines_lds_fused<false, const cplx*>(oth, cur, a.pw.ns, a.pw.tw, Hp, 1, W, ss.w, ss.mLw,
-                                                          RowLoad{a, b, H}, NoFuse{});
-            oth = cur == buf0 ? buf1 : buf0;
-            STAMP(2);
-            STAMP(3);
-        } else {
-            // load: line r = rows (2r, 2r+1)
-            // (two entries per trip, all their loads asked for before the first is used: one memory round trip for a
-            // 35 x 60 lattice on 576 threads instead of two -- a round trip is 0.5 us in HBM and 2.5 us when the host-pointer
-            // entry points let the kernel read the caller's arrays in pinned host memory)
-            for (int w = threadIdx.x; w < Hp * W; w += 2 * blockDim.x) {
-                const int w1 = w + (int)blockDim.x;
-                const bool two = w1 < Hp * W;
-                const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
-                const int r1 = two ? (int)fastdiv((unsigned)w1, (unsigned)W, mW) : r, j1 = two ? w1 - r1 * W : j;
-                const double re = in_transform<OP>(a, b, 2 * r, j);
-                const double im = (2 * r + 1 < H) ? in_transform<OP>(a, b, 2 * r + 1, j) : 0.0;
-                const double re1 = in_transform<OP>(a, b, 2 * r1, j1);
-                const double im1 = (2 * r1 + 1 < H) ? in_transform<OP>(a, b, 2 * r1 + 1, j1) : 0.0;
-                cur[w] = make_double2(re, im);
-                if (two) cur[w1] = make_double2(re1, im1);
-            }
-            __syncthreads();
-            STAMP(2);
-            LdsLine res = fft_w(std::false_type{}, cur, oth, Hp, 1, W);
-            if (res != cur) {
-                oth = cur;
-                cur = res;
-            }
-            STAMP(3);
+        __syncthreads();
+        {
+            const LdsLine t = cur;
+            cur = oth;
+            oth = t;
         }
-        if (ss.fuse_h) { // (the first column stage separates the row pairs as it reads them)
-            STAMP(4);
-            cur = fft_lines_lds_fused<false, const cplx*>(cur, oth, a.ph.ns, a.ph.tw, NC, sS, 1, ss.h, ss.mLh,
-                                                          SplitLoad{cur, W, weven}, NoFuse{});
-            oth = cur == buf0 ? buf1 : buf0;
-            STAMP(5);
-        } else {
-            // split row pairs -> packed spectrum S[i * sS + jp] in `oth`
-            for (int w = threadIdx.x; w < H * NC; w += blockDim.x) {
-                const int i = (int)fastdiv((unsigned)w, (unsigned)NC, mNC), jp = w - i * NC;
-                const LdsLine line = cur + (i >> 1) * W;
-                auto rowspec = [&](int j) -> cplx {
-                    const cplx z = line[j];
-                    const cplx zc = line[j == 0 ? 0 : W - j];
-                    // A = (Z + conj Zc)/2 (even row) ; B = (Z - conj Zc)/(2i) (odd row)
-                    if ((i & 1) == 0) return make_double2(0.5 * (z.x + zc.x), 0.5 * (z.y - zc.y));
-                    return make_double2(0.5 * (z.y + zc.y), -0.5 * (z.x - zc.x));
-                };
-                cplx v;
-                if (jp == 0) {
-                    v.x = rowspec(0).x;
-                    v.y = weven ? rowspec(W / 2).x : 0.0;
-                } else {
-                    v = rowspec(jp);
-                }
-                oth[i * sS + jp] = v;
-            }
-            __syncthreads();
-            {
-                const LdsLine t = cur;
-                cur = oth;
-                oth = t;
-            }
-            STAMP(4);
-            const LdsLine res = fft_h(std::false_type{}, cur, oth, NC, sS, 1);
-            if (res != cur) {
-                oth = cur;
-                cur = res;
-            }
-            STAMP(5);
+        STAMP(4);
+        res = fft_h(std::false_type{}, cur, oth, NC, sS, 1);
+        if (res != cur) {
+            oth = cur;
+            cur = res;
         }
+        STAMP(5);
     }
 
     // elementwise stage on S = cur
@@ -358,79 +308,40 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
             cur = res;
         }
         STAMP(9);
-        if (ss.fuse_w) {
-            // the first inverse row stage merges the row pairs as it reads them, the last one stores the lattice
-            struct MergeLoad {
-                LdsLine S;
-                int sS, W, H;
-                bool weven;
-                __device__ __forceinline__ cplx load(int r, int j) const {
-                    auto rowspec = [&](int i, int jj) -> cplx {
-                        const bool mir = jj > W / 2;
-                        const int q = mir ? W - jj : jj;
-                        cplx v;
-                        if (q == 0) v = make_double2(cplx(S[i * sS]).x, 0.0);
-                        else if (weven && q == W / 2) v = make_double2(cplx(S[i * sS]).y, 0.0);
-                        else v = S[i * sS + q];
-                        if (mir) v.y = -v.y;
-                        return v;
-                    };
-                    const cplx A = rowspec(2 * r, j);
-                    cplx Bv = make_double2(0.0, 0.0);
-                    if (2 * r + 1 < H) Bv = rowspec(2 * r + 1, j);
-                    return make_double2(A.x - Bv.y, A.y + Bv.x);
-                }
+        // merge row pairs into complex lines of length W in `oth`
+        for (int w = threadIdx.x; w < Hp * W; w += blockDim.x) {
+            const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
+            auto rowspec = [&](int i, int jj) -> cplx {
+                const bool mir = jj > W / 2;
+                const int q = mir ? W - jj : jj;
+                cplx v;
+                if (q == 0) v = make_double2(cplx(cur[i * sS]).x, 0.0);
+                else if (weven && q == W / 2) v = make_double2(cplx(cur[i * sS]).y, 0.0);
+                else v = cur[i * sS + q];
+                if (mir) v.y = -v.y;
+                return v;
             };
-            struct OutStore {
-                const LatArgs& a;
-                int64_t b;
-                int H, W;
-                __device__ __forceinline__ void store(int r, int j, const cplx& v) const {
-                    double* o = a.out + b * (int64_t)H * W;
-                    o[(int64_t)(2 * r) * W + j] = out_transform<OP>(a, b, 2 * r, j, v.x);
-                    if (2 * r + 1 < H) o[(int64_t)(2 * r + 1) * W + j] = out_transform<OP>(a, b, 2 * r + 1, j, v.y);
-                }
-            };
-            STAMP(10);
-            (void)fft_lines_lds_fused<true, const cplx*>(cur, oth, a.pw.ns, a.pw.tw, Hp, 1, W, ss.w, ss.mLw,
-                                                         MergeLoad{cur, sS, W, H, weven}, OutStore{a, b, H, W});
-            STAMP(11);
-        } else {
-            // merge row pairs into complex lines of length W in `oth`
-            for (int w = threadIdx.x; w < Hp * W; w += blockDim.x) {
-                const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
-                auto rowspec = [&](int i, int jj) -> cplx {
-                    const bool mir = jj > W / 2;
-                    const int q = mir ? W - jj : jj;
-                    cplx v;
-                    if (q == 0) v = make_double2(cplx(cur[i * sS]).x, 0.0);
-                    else if (weven && q == W / 2) v = make_double2(cplx(cur[i * sS]).y, 0.0);
-                    else v = cur[i * sS + q];
-                    if (mir) v.y = -v.y;
-                    return v;
-                };
-                const cplx A = rowspec(2 * r, j);
-                cplx Bv = make_double2(0.0, 0.0);
-                if (2 * r + 1 < H) Bv = rowspec(2 * r + 1, j);
-                oth[w] = make_double2(A.x - Bv.y, A.y + Bv.x);
-            }
-            __syncthreads();
-            {
-                const LdsLine t = cur;
-                cur = oth;
-                oth = t;
-            }
-            STAMP(10);
-            res = fft_w(std::true_type{}, cur, oth, Hp, 1, W);
-            STAMP(11);
-            for (int w = threadIdx.x; w < Hp * W; w += blockDim.x) {
-                const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
-                const cplx v = res[w];
-                double* o = a.out + b * (int64_t)H * W;
-                o[(int64_t)(2 * r) * W + j] = out_transform<OP>(a, b, 2 * r, j, v.x);
-                if (2 * r + 1 < H) o[(int64_t)(2 * r + 1) * W + j] = out_transform<OP>(a, b, 2 * r + 1, j, v.y);
-            }
-            }
+            const cplx A = rowspec(2 * r, j);
+            cplx Bv = make_double2(0.0, 0.0);
+            if (2 * r + 1 < H) Bv = rowspec(2 * r + 1, j);
+            oth[w] = make_double2(A.x - Bv.y, A.y + Bv.x);
+        }
+        __syncthreads();
+        {
+            const LdsLine t = cur;
+            cur = oth;
+            oth = t;
+        }
+        STAMP(10);
+        res = fft_w(std::true_type{}, cur, oth, Hp, 1, W);
+        STAMP(11);
+        for (int w = threadIdx.x; w < Hp * W; w += blockDim.x) {
+            const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
+            const cplx v = res[w];
+            double* o = a.out + b * (int64_t)H * W;
+            o[(int64_t)(2 * r) * W + j] = out_transform<OP>(a, b, 2 * r, j, v.x);
+            if (2 * r + 1 < H) o[(int64_t)(2 * r + 1) * W + j] = out_transform<OP>(a, b, 2 * r + 1, j, v.y);
+        }
     }
     if (ss.done_flag) { // (uniform; one workgroup: batch == 1)
         // every thread's results are out at system scope, then ONE release store of the sequence number the host spins on
@@ -460,15 +371,6 @@ hipError_t launch_small_t(const LatArgs& a, int cap, int sS, int nthreads, size_
     };
     fill(a.pw, ss.w);
     fill(a.ph, ss.h);
-    auto fusable = [](const LinePlan& p) {
-        static const bool off = [] { const char* e = getenv("GPT_SMALL_FUSE"); return e && e[0] == '0'; }(); // (A/B timing)
-        if (off || p.ns < 1 || p.ns > GPT_MAX_STAGES) return 0;
-        for (int s = 0; s < p.ns; ++s)
-            if (!radix_has_butterfly(p.r[s])) return 0;
-        return 1;
-    };
-    ss.fuse_w = fusable(a.pw);
-    ss.fuse_h = fusable(a.ph);
     ss.mLw = fastdiv_magic_hd((unsigned)((a.H + 1) / 2));
     ss.mLh = ss.mNC = fastdiv_magic_hd((unsigned)(1 + (a.W - 1) / 2));
     ss.mW = fastdiv_magic_hd((unsigned)a.W);
