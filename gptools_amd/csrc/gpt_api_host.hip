@@ -73,6 +73,10 @@ struct Stager {
         }
         return false;
     }
+    bool host_visible(const void* dev_ptr) const {
+        const char* p = static_cast<const char*>(dev_ptr);
+        return tiny && p >= c->bounce_dev && p < c->bounce_dev + c->bounce_bytes;
+    }
     // the two views of the bounce area
     void* to_dev(char* host_ptr) { return c->bounce_dev + (host_ptr - c->bounce); }
     char* to_host(const void* dev_ptr) { return c->bounce + (static_cast<const char*>(dev_ptr) - c->bounce_dev); }
@@ -366,11 +370,17 @@ int gpt_gp_inv_rfft2_obs_lpdf_host(gpt_ctx* c, int layout, int family, const dou
     double* dsc = (double*)s.dev(1, 8, 8); // theta, lp, d/dloc sum, d/dtheta, min_eig
     if (s.go()) return s.rc;
     if (dfill) {
-        HIP_TRY(c, gpt_launch_fill(dfill, H * W, loc_scalar, c->stream));
+        if (s.host_visible(dfill)) { // (a small call: its arrays live in the pinned bounce area -- fill it from here)
+            double* hf = reinterpret_cast<double*>(s.to_host(dfill));
+            for (int64_t i = 0; i < H * W; ++i) hf[i] = loc_scalar;
+        } else {
+            HIP_TRY(c, gpt_launch_fill(dfill, H * W, loc_scalar, c->stream));
+        }
         dl = dfill;
     }
     s.put(dsc, theta);
     if (s.rc) return s.rc;
+    s.arm(); // (taken up only by the one-launch route for lattices that fit a workgroup, gpt_api_obs.hip)
     if ((rc = gpt_gp_inv_rfft2_obs_lpdf_vjp(c, family, dz, 0, dl, 0, dc, 0, dob, 0, oh, ow,
                                             family == GPT_OBS_POISSON_LOG ? nullptr : dsc, prior, H, W, 1, dim1, dsc + 1,
                                             nullptr, dgz, nullptr, dsc + 2, dgc, dsc + 3, dsc + 4)))

@@ -90,9 +90,49 @@ int gpt_gp_inv_rfft2_obs_lpdf_vjp(gpt_ctx* c, int family, const double* z, int64
     if (family != GPT_OBS_POISSON_LOG && !theta) return fail(c, GPT_ERR_SHAPE, "this observation family needs theta");
     if (oh < 1 || ow < 1 || oh > H || ow > W)
         return fail(c, GPT_ERR_SHAPE, "the observed window must lie inside the lattice");
+    // (a request of the host entry point to let the LAST launch publish its completion, gpt_ctx::done_*: only the
+    // one-launch route below may take it up -- the composed route's first lattice launch must not)
+    const bool armed = c->done_armed;
+    c->done_armed = false;
     if (batch == 0) return GPT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const int64_t hw = H * W, hwf = H * (W / 2 + 1);
+    // Lattices that fit one workgroup's LDS (the docs models: 35 x 60, n = 100 ... 200): the whole density in ONE launch,
+    // the lattice never leaves LDS (gpt_small_obs.hip; GPT_OBS_SMALL_FUSED=0: the composed route, for A/B timing).
+    static const bool small_fused_off = [] { const char* e = getenv("GPT_OBS_SMALL_FUSED"); return e && e[0] == '0'; }();
+    if (!small_fused_off && path_for_shape(H, W) == 0) {
+        LatArgs a = base_args(H, W, batch, dim1);
+        if ((rc = make_plan(c, a.W, a.pw, false)) != GPT_OK) return rc;
+        if ((rc = make_plan(c, a.H, a.ph, false)) != GPT_OK) return rc;
+        a.x = z; a.x_bs = z_bs;
+        a.cov = cov; a.cov_bs = cov_bs;
+        a.out = grad_z;
+        a.out_cov = grad_cov;
+        if (!grad_cov) {
+            if ((rc = ensure(c, c->sink, c->sink_bytes, sizeof(double) * (size_t)batch * hwf))) return rc;
+            a.out_cov = c->sink;
+        }
+        a.zprior = prior ? 1 : 0;
+        a.min_eig = min_eig;
+        SmallObsArgs o;
+        o.loc = loc; o.loc_bs = loc_bs;
+        o.obs = obs; o.obs_bs = obs_bs;
+        o.oh = (int)oh; o.ow = (int)ow; o.family = family;
+        o.theta = theta;
+        o.f_out = f_out;
+        o.grad_loc = grad_loc;
+        o.lp = lp;
+        o.grad_theta = grad_theta;
+        o.grad_loc_sum = grad_loc_sum;
+        unsigned long long* flag = nullptr;
+        if (armed && batch == 1 && c->done_dev) {
+            flag = c->done_dev;
+            c->done_published = true;
+            ++c->done_seq;
+        }
+        HIP_TRY(c, gpt_launch_small_obs(a, o, c->stream, flag, c->done_seq));
+        return GPT_OK;
+    }
     // GPT_OBS_FUSED=1 (read per call): one row kernel does inverse rows -> observation model -> forward rows in place
     // on the workspace. Same results; measured slower than the three composed steps on MI355X (200
     // VGPRs leave two waves per SIMD to hide the densities' dependent chains), so it is off unless asked for.

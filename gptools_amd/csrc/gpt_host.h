@@ -136,3 +136,20 @@ hipError_t gpt_launch_obs(const ObsArgs& a, double* partials, hipStream_t st);
 hipError_t gpt_launch_obs_combine(const double* sums, const double* psum, int64_t batch, double* lp, double* grad_theta,
                                   double* grad_loc_sum, double* nobs, hipStream_t st);
 hipError_t gpt_launch_fill(double* p, int64_t n, double v, hipStream_t st);
+// The same model density in ONE launch for lattices that fit a workgroup's LDS (gpt_small_obs.hip). `a` as for OP_INV_VJP
+// (x = z, cov, out = d/dz, out_cov = d/dcov -- never null --, zprior, min_eig), plans made; the rest here.
+struct SmallObsArgs {
+    const double* loc; // [batch][H][W], loc_bs apart (0 = shared), or null (0 everywhere)
+    int64_t loc_bs;
+    const double* obs; // [batch][oh][ow], obs_bs apart (0 = shared)
+    int64_t obs_bs;
+    int oh, ow, family;
+    const double* theta; // [batch] or null
+    double* f_out;       // [batch][H][W] or null
+    double* grad_loc;    // [batch][H][W] or null: d lp / d f
+    double* lp;          // [batch]
+    double* grad_theta;  // [batch] or null
+    double* grad_loc_sum; // [batch] or null
+};
+hipError_t gpt_launch_small_obs(const LatArgs& a, const SmallObsArgs& o, hipStream_t st,
+                                unsigned long long* done_flag = nullptr, unsigned long long done_seq = 0);

@@ -60,21 +60,9 @@ extern "C" int gpt_debug_small_stage_stamps(long long* out, int n) {
 // a path that is nothing but latency (one 35 x 60 lattice: ~20 barrier-separated phases).
 #define GPT_LDS_FFT_INLINE __forceinline__
 #include "gpt_lds_fft.h"
-
-#define GPT_SMALL_HDR 1024 // bytes of LDS in front of the two line buffers (the reduction's per-wave slots)
+#include "gpt_small_phases.h"
 
 namespace {
-
-// Stage constants of the two line plans, made on the host once per launch (StageK, gpt_lds_fft.h), and the division magics
-// of the two line counts: (H + 1) / 2 row pairs, 1 + (W - 1) / 2 packed columns.
-struct SmallStages {
-    StageK w[GPT_MAX_STAGES], h[GPT_MAX_STAGES];
-    unsigned mLw, mLh;
-    unsigned mW, mNC, mwc; // magics of the element loops: W, NC = 1 + (W - 1) / 2, max((W - 1) / 2, 1)
-    // one-lattice launches of the host-pointer entry points: where to publish completion (gpt_ctx::done_*), or null
-    unsigned long long* done_flag;
-    unsigned long long done_seq;
-};
 
 template <int OP>
 __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap, int sS, SmallStages ss) {
@@ -120,27 +108,8 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
 
     // cov of this thread's first elementwise entries, asked for now: by the time the transforms are through they are in
     // registers, instead of a memory round trip in the middle of the kernel
-    constexpr bool USES_COV = OP != OP_RFFT2 && OP != OP_INV_RFFT2 && !op_is_kvjp(OP);
-    const int tail = (int)blockDim.x - 1 - (int)threadIdx.x; // work item of the packed-column loop: (row k, edge column)
-    double pre_ci = 1.0, pre_ci1 = 1.0, pre_c = 1.0, pre_cm = 1.0;
-    if (USES_COV) {
-        const double* cov_b = a.cov + b * a.cov_bs;
-        if ((int)threadIdx.x < H * L.wc) {
-            const int i = (int)fastdiv(threadIdx.x, (unsigned)L.wc, mwc), j = 1 + ((int)threadIdx.x - i * L.wc);
-            pre_ci = cov_b[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
-        }
-        if ((int)(threadIdx.x + blockDim.x) < H * L.wc) { // ... and of its second
-            const unsigned w1 = threadIdx.x + blockDim.x;
-            const int i = (int)fastdiv(w1, (unsigned)L.wc, mwc), j = 1 + ((int)w1 - i * L.wc);
-            pre_ci1 = cov_b[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
-        }
-        const int k = tail >> 1, e = tail & 1;
-        if (k <= H / 2 && (e == 0 || weven)) {
-            const int j = e ? W / 2 : 0;
-            pre_c = cov_b[(unsigned)k * (unsigned)L.Wf + (unsigned)j];
-            pre_cm = cov_b[(unsigned)(k ? H - k : 0) * (unsigned)L.Wf + (unsigned)j];
-        }
-    }
+    SmallCovPre pre = {1.0, 1.0, 1.0, 1.0};
+    if (small_uses_cov<OP>()) pre = small_cov_prefetch(a.cov + b * a.cov_bs, L, H, W, mwc, weven);
     STAMP(1);
     if (op_has_fwd(OP)) {
         // load: line r = rows (2r, 2r+1)
@@ -168,25 +137,7 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         }
         STAMP(3);
         // split row pairs -> packed spectrum S[i * sS + jp] in `oth`
-        for (int w = threadIdx.x; w < H * NC; w += blockDim.x) {
-            const int i = (int)fastdiv((unsigned)w, (unsigned)NC, mNC), jp = w - i * NC;
-            const LdsLine line = cur + (i >> 1) * W;
-            auto rowspec = [&](int j) -> cplx {
-                const cplx z = line[j];
-                const cplx zc = line[j == 0 ? 0 : W - j];
-                // A = (Z + conj Zc)/2 (even row) ; B = (Z - conj Zc)/(2i) (odd row)
-                if ((i & 1) == 0) return make_double2(0.5 * (z.x + zc.x), 0.5 * (z.y - zc.y));
-                return make_double2(0.5 * (z.y + zc.y), -0.5 * (z.x - zc.x));
-            };
-            cplx v;
-            if (jp == 0) {
-                v.x = rowspec(0).x;
-                v.y = weven ? rowspec(W / 2).x : 0.0;
-            } else {
-                v = rowspec(jp);
-            }
-            oth[i * sS + jp] = v;
-        }
+        small_split(cur, oth, H, W, NC, sS, mNC, weven);
         __syncthreads();
         {
             const LdsLine t = cur;
@@ -207,50 +158,10 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
     EwPtrs P = op_is_kvjp(OP) ? P_early : make_ptrs(a, b);
     EwAcc acc;
     acc_init(acc);
-    for (int w = threadIdx.x; w < H * L.wc; w += blockDim.x) {
-        const int i = (int)fastdiv((unsigned)w, (unsigned)L.wc, mwc), j = 1 + (w - i * L.wc);
-        const cplx F = cur[i * sS + j];
-        double c = 1.0;
-        if (USES_COV)
-            c = (w == (int)threadIdx.x) ? pre_ci
-                                        : (w == (int)(threadIdx.x + blockDim.x)) ? pre_ci1
-                                                                                 : P.cov[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
-        const cplx G = ew_interior_c<OP>(a, L, P, i, j, F, c, acc);
-        if (op_has_inv(OP)) cur[i * sS + j] = G;
-        acc_renorm(acc);
-    }
-    acc_fold(acc);
+    small_interior<OP>(a, L, P, cur, sS, H, mwc, pre, acc);
     STAMP(6);
     STAMP_LAST(21);
-    // Packed column 0 = edge column 0 + i * edge column W/2: TWO lanes per row pair (k, H - k), one per edge column, so
-    // that the two divisions and logarithms of a row run side by side, and on the LAST threads of the workgroup, whose
-    // waves have the fewest interior entries (the two loops then overlap instead of queueing up on the first wave).
-    // Lane pairs (t, t ^ 1) swap their results through DPP.
-    for (int t = tail; (t >> 1) <= H / 2; t += blockDim.x) {
-        const int k = t >> 1, e = t & 1;
-        const int km = k ? H - k : 0; // (H - k) % H
-        const cplx Zk = cur[k * sS], Zm = cur[km * sS];
-        // A = (Zk + conj Zm) / 2 (column 0) ; B = (Zk - conj Zm) / (2i) (column W/2)
-        cplx V = e ? make_double2(0.5 * (Zk.y + Zm.y), -0.5 * (Zk.x - Zm.x)) : make_double2(0.5 * (Zk.x + Zm.x), 0.5 * (Zk.y - Zm.y));
-        if (e == 0 || weven) {
-            const int j = e ? W / 2 : 0;
-            double c = 1.0, cm = 1.0;
-            if (USES_COV) {
-                c = (t == tail) ? pre_c : P.cov[(unsigned)k * (unsigned)L.Wf + (unsigned)j];
-                cm = (t == tail) ? pre_cm : P.cov[(unsigned)km * (unsigned)L.Wf + (unsigned)j];
-            }
-            V = ew_edge_c<OP>(a, L, P, k, j, V, c, cm, acc);
-        } else {
-            V = make_double2(0.0, 0.0);
-        }
-        if (op_has_inv(OP)) {
-            const cplx O = make_double2(dpp_f64<0xB1, 0xf>(0.0, V.x), dpp_f64<0xB1, 0xf>(0.0, V.y)); // the other lane's
-            const cplx A = e ? O : V, B = e ? V : O;
-            // Z[k] = A + iB ; Z[H-k] = conj(A) + i conj(B)
-            if (e == 0) cur[k * sS] = make_double2(A.x - B.y, A.y + B.x);
-            else if (km != k) cur[km * sS] = make_double2(A.x + B.y, -A.y + B.x);
-        }
-    }
+    small_packed0<OP>(a, L, P, cur, sS, H, W, weven, pre, acc); // (on the tail threads: beside the interior, not after it)
     STAMP(7);
     STAMP_LAST(22);
     // Reduction of the log density (and the kernel-fused op's three sums): every wave leaves its sums in `red`, the
@@ -309,23 +220,7 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         }
         STAMP(9);
         // merge row pairs into complex lines of length W in `oth`
-        for (int w = threadIdx.x; w < Hp * W; w += blockDim.x) {
-            const int r = (int)fastdiv((unsigned)w, (unsigned)W, mW), j = w - r * W;
-            auto rowspec = [&](int i, int jj) -> cplx {
-                const bool mir = jj > W / 2;
-                const int q = mir ? W - jj : jj;
-                cplx v;
-                if (q == 0) v = make_double2(cplx(cur[i * sS]).x, 0.0);
-                else if (weven && q == W / 2) v = make_double2(cplx(cur[i * sS]).y, 0.0);
-                else v = cur[i * sS + q];
-                if (mir) v.y = -v.y;
-                return v;
-            };
-            const cplx A = rowspec(2 * r, j);
-            cplx Bv = make_double2(0.0, 0.0);
-            if (2 * r + 1 < H) Bv = rowspec(2 * r + 1, j);
-            oth[w] = make_double2(A.x - Bv.y, A.y + Bv.x);
-        }
+        small_merge(cur, oth, H, W, Hp, sS, mW, weven);
         __syncthreads();
         {
             const LdsLine t = cur;
@@ -359,22 +254,7 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
 template <int OP>
 hipError_t launch_small_t(const LatArgs& a, int cap, int sS, int nthreads, size_t lds, hipStream_t st,
                           unsigned long long* done_flag, unsigned long long done_seq) {
-    SmallStages ss;
-    ss.done_flag = a.batch == 1 ? done_flag : nullptr;
-    ss.done_seq = done_seq;
-    auto fill = [](const LinePlan& p, StageK* k) {
-        int Ns = 1;
-        for (int s = 0; s < p.ns && s < GPT_MAX_STAGES; ++s) {
-            k[s] = stage_consts(p.n, p.r[s], Ns);
-            Ns *= p.r[s];
-        }
-    };
-    fill(a.pw, ss.w);
-    fill(a.ph, ss.h);
-    ss.mLw = fastdiv_magic_hd((unsigned)((a.H + 1) / 2));
-    ss.mLh = ss.mNC = fastdiv_magic_hd((unsigned)(1 + (a.W - 1) / 2));
-    ss.mW = fastdiv_magic_hd((unsigned)a.W);
-    ss.mwc = fastdiv_magic_hd((unsigned)((a.W - 1) / 2 > 0 ? (a.W - 1) / 2 : 1));
+    const SmallStages ss = make_small_stages(a, done_flag, done_seq);
     // The attribute belongs to (kernel, device): one bit per device, set from any thread (raising the cap twice is
     // harmless, so a lost race costs one extra call).
     static std::atomic<uint64_t> attr_set{0};
@@ -405,28 +285,33 @@ bool gpt_small_fits(int H, int W, int* cap_out, int* stride_out) {
     return GPT_SMALL_HDR + 2 * cap * (int64_t)sizeof(cplx) <= 160 * 1024;
 }
 
+int gpt_small_threads(int H, int W, int64_t batch) {
+    int64_t work = (int64_t)H * W / 4;
+    int nthreads = (int)((work + 63) / 64 * 64);
+    if (nthreads < 64) nthreads = 64;
+    // short and wide (the 1-D functions: H = 1): the element loops run over W entries and are most of such a call -- a
+    // thread per entry up to 256 (n = 160, 64 chains: 12.25 us at 64 threads, 10.7 at 192; profiles/r03_k_small_threads.jsonl)
+    const int wide = W < 256 ? (W + 63) / 64 * 64 : 256;
+    if (nthreads < wide) nthreads = wide;
+    if (nthreads > 1024) nthreads = 1024;
+    // Many lattices per launch: throughput, not latency -- four-wave workgroups let four lattices share a CU
+    // (measured at 35 x 60 with 4096 chains: 369 us at 576 threads, 166 us at 256; with 64 chains 24.5 against 26.9)
+    if (batch >= 512 && nthreads > 256) nthreads = 256;
+    static const int forced = [] { // GPT_SMALL_THREADS=<n>: tuning experiments
+        const char* e = getenv("GPT_SMALL_THREADS");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced >= 64 && forced <= 1024) nthreads = forced / 64 * 64;
+    return nthreads;
+}
+
 hipError_t gpt_launch_small(int op, const LatArgs& a, hipStream_t st, unsigned long long* done_flag,
                             unsigned long long done_seq) {
     int cap, sS;
     if (!gpt_small_fits(a.H, a.W, &cap, &sS)) return hipErrorInvalidValue;
     if (a.batch <= 0) return hipSuccess;
     size_t lds = GPT_SMALL_HDR + 2 * (size_t)cap * sizeof(cplx);
-    int64_t work = (int64_t)a.H * a.W / 4;
-    int nthreads = (int)((work + 63) / 64 * 64);
-    if (nthreads < 64) nthreads = 64;
-    // short and wide (the 1-D functions: H = 1): the element loops run over W entries and are most of such a call -- a
-    // thread per entry up to 256 (n = 160, 64 chains: 12.25 us at 64 threads, 10.7 at 192; profiles/r03_k_small_threads.jsonl)
-    const int wide = a.W < 256 ? (a.W + 63) / 64 * 64 : 256;
-    if (nthreads < wide) nthreads = wide;
-    if (nthreads > 1024) nthreads = 1024;
-    // Many lattices per launch: throughput, not latency -- four-wave workgroups let four lattices share a CU
-    // (measured at 35 x 60 with 4096 chains: 369 us at 576 threads, 166 us at 256; with 64 chains 24.5 against 26.9)
-    if (a.batch >= 512 && nthreads > 256) nthreads = 256;
-    static const int forced = [] { // GPT_SMALL_THREADS=<n>: tuning experiments
-        const char* e = getenv("GPT_SMALL_THREADS");
-        return e ? atoi(e) : 0;
-    }();
-    if (forced >= 64 && forced <= 1024) nthreads = forced / 64 * 64;
+    const int nthreads = gpt_small_threads(a.H, a.W, a.batch);
     switch (op) {
     case OP_RFFT2: return launch_small_t<OP_RFFT2>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);
     case OP_INV_RFFT2: return launch_small_t<OP_INV_RFFT2>(a, cap, sS, nthreads, lds, st, done_flag, done_seq);

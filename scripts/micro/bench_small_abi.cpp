@@ -101,6 +101,56 @@ int main() {
         fflush(stdout);
         CK(hipFree(dy)); CK(hipFree(dl)); CK(hipFree(dc)); CK(hipFree(dlp)); CK(hipFree(dgy)); CK(hipFree(dgc)); CK(hipFree(dmn));
     }
+    // The non-centred model density of docs/trees (trees.stan:31-49): z -> f = gp_inv_rfft2(z, loc, cov) -> negative-binomial
+    // counts on the 25 x 50 corner of the 35 x 60 padded lattice (10 % masked) -> reverse mode, white-noise prior included.
+    // Device pointers (1 / 64 / 4096 chains per launch) and the host-pointer call Stan makes (column-major, one chain).
+    for (int64_t batch : {1, 64, 4096}) {
+        const int64_t H = 35, W = 60, oh = 25, ow = 50, Wf = W / 2 + 1, n = H * W;
+        std::vector<double> z(batch * n), cov(H * Wf), obs(oh * ow), th(batch, 1.7);
+        for (auto& v : z) v = nd(g);
+        for (auto& v : cov) v = std::exp(0.3 * nd(g));
+        for (auto& v : obs) { v = std::floor(std::fabs(2.0 * nd(g))); if (std::fabs(nd(g)) > 1.64) v = -1.0; }
+        double *dz, *dc, *dob, *dth, *dlp, *dgz, *dgc, *dgt, *dgl, *dmn, *dloc;
+        CK(hipMalloc(&dz, z.size() * 8)); CK(hipMalloc(&dc, cov.size() * 8)); CK(hipMalloc(&dob, obs.size() * 8));
+        CK(hipMalloc(&dth, batch * 8)); CK(hipMalloc(&dlp, batch * 8)); CK(hipMalloc(&dgz, z.size() * 8));
+        CK(hipMalloc(&dgc, batch * H * Wf * 8)); CK(hipMalloc(&dgt, batch * 8)); CK(hipMalloc(&dgl, batch * 8));
+        CK(hipMalloc(&dmn, batch * 8)); CK(hipMalloc(&dloc, n * 8));
+        std::vector<double> loc(n, 0.5);
+        CK(hipMemcpy(dz, z.data(), z.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dc, cov.data(), cov.size() * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dob, obs.data(), obs.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dth, th.data(), batch * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dloc, loc.data(), n * 8, hipMemcpyHostToDevice));
+        auto call = [&] {
+            GK(gpt_gp_inv_rfft2_obs_lpdf_vjp(ctx, GPT_OBS_NEG_BINOMIAL_2_LOG, dz, n, dloc, 0, dc, 0, dob, 0, oh, ow, dth, 1, H, W, batch, 0,
+                                             dlp, nullptr, dgz, nullptr, dgl, dgc, dgt, dmn));
+        };
+        for (int i = 0; i < 20; ++i) call();
+        CK(hipStreamSynchronize(st));
+        const int it = batch > 1000 ? 300 : 2000;
+        double t0 = now();
+        for (int i = 0; i < it; ++i) call();
+        CK(hipStreamSynchronize(st));
+        const double us_dev = 1e6 * (now() - t0) / it;
+        double us_host = -1.0;
+        if (batch == 1) {
+            double lp, gt, gl;
+            std::vector<double> gz(n), gc(H * Wf);
+            auto host_call = [&] {
+                const int rc = gpt_gp_inv_rfft2_obs_lpdf_host(ctx, GPT_COL_MAJOR, GPT_OBS_NEG_BINOMIAL_2_LOG, z.data(), nullptr, 0.5, cov.data(),
+                                                              obs.data(), oh, ow, 1.7, 1, H, W, 0, &lp, gz.data(), &gl, gc.data(), &gt);
+                if (rc != GPT_OK) { printf("host call -> %d: %s\n", rc, gpt_last_error(ctx)); exit(1); }
+            };
+            for (int i = 0; i < 20; ++i) host_call();
+            t0 = now();
+            for (int i = 0; i < 500; ++i) host_call();
+            us_host = 1e6 * (now() - t0) / 500;
+        }
+        printf("{\"case\": \"trees model density: 35x60, 25x50 negative-binomial counts, %lld chain(s) per launch\", "
+               "\"us_per_call_device_ptr\": %.2f, \"evals_per_s_device_ptr\": %.0f, \"us_per_call_host_ptr_col_major\": %.2f}\n",
+               (long long)batch, us_dev, batch / (1e-6 * us_dev), us_host);
+        fflush(stdout);
+        CK(hipFree(dz)); CK(hipFree(dc)); CK(hipFree(dob)); CK(hipFree(dth)); CK(hipFree(dlp)); CK(hipFree(dgz)); CK(hipFree(dgc));
+        CK(hipFree(dgt)); CK(hipFree(dgl)); CK(hipFree(dmn)); CK(hipFree(dloc));
+    }
     gpt_destroy(ctx);
     return 0;
 }
