@@ -47,6 +47,9 @@ _SIGNATURES = {
     "gpt_gp_inv_rfft2_obs_lpdf_vjp": [c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr,
                                       c_int, c_i64, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                       c_ptr],
+    "gpt_gp_inv_rfft2_obs_lpdf_kernel_vjp": [c_int, c_int, c_dbl, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_dbl, c_ptr, c_i64,
+                                             c_i64, c_i64, c_ptr, c_int, c_i64, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr,
+                                             c_ptr, c_ptr, c_ptr],
     # host-pointer entry points
     "gpt_gp_rfft2_host": [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr],
     "gpt_gp_inv_rfft2_host": [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr],
@@ -54,6 +57,8 @@ _SIGNATURES = {
     "gpt_gp_rfft2_lpdf_host": [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr],
     "gpt_gp_inv_rfft2_obs_lpdf_host": [c_int, c_int, c_ptr, c_ptr, c_dbl, c_ptr, c_ptr, c_i64, c_i64, c_dbl, c_int, c_i64,
                                        c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "gpt_gp_inv_rfft2_obs_lpdf_kernel_host": [c_int, c_int, c_int, c_dbl, c_ptr, c_ptr, c_dbl, c_ptr, c_dbl, c_ptr, c_i64,
+                                              c_i64, c_dbl, c_int, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "gpt_gp_inv_rfft2_vjp_host": [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr],
     "gpt_gp_rfft2_vjp_host": [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr],
     "gpt_rfft2_host": [c_int, c_ptr, c_i64, c_i64, c_ptr],

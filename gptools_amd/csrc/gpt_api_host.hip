@@ -394,6 +394,57 @@ int gpt_gp_inv_rfft2_obs_lpdf_host(gpt_ctx* c, int layout, int family, const dou
     return s.finish(dsc + 4);
 }
 
+// The same with the spectrum given by its kernel parameters (gpt_gp_inv_rfft2_obs_lpdf_kernel_vjp): five numbers go up
+// and five come back where the array form moves two H x (W/2+1) arrays each way.
+int gpt_gp_inv_rfft2_obs_lpdf_kernel_host(gpt_ctx* c, int layout, int family, int matern, double nu, const double* z,
+                                          const double* loc, double loc_scalar, const double* params, double nugget,
+                                          const double* obs, int64_t oh, int64_t ow, double theta, int prior, int64_t H,
+                                          int64_t W, int dim1, double* lp, double* grad_z, double* grad_loc_sum,
+                                          double* params_bar, double* grad_theta) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    if (!z || !params || !obs || !lp || !grad_z)
+        return fail(c, GPT_ERR_SHAPE, "z, params, obs, lp and grad_z must not be null");
+    if (oh < 1 || ow < 1 || oh > H || ow > W)
+        return fail(c, GPT_ERR_SHAPE, "the observed window must lie inside the lattice");
+    if (family != GPT_OBS_POISSON_LOG && !(theta > 0 && std::isfinite(theta)))
+        return fail(c, GPT_ERR_SHAPE, family == GPT_OBS_NORMAL ? "Scale parameter must be positive finite"
+                                                               : "Precision parameter must be positive finite");
+    const int npar = dim1 ? 3 : 5;
+    Stager s(c, layout, arena_need(H, W, 6));
+    const double* dz = (const double*)s.up(z, H, W, 8);
+    const double* dob = (const double*)s.up(obs, oh, ow, 8);
+    const double* dl = (const double*)s.up(loc, H, W, 8);
+    const double* dpar = (const double*)s.up(params, 1, npar, 8);
+    double* dfill = loc ? nullptr : (double*)s.dev(H, W, 8);
+    double* dgz = (double*)s.dev(H, W, 8);
+    double* dsc = (double*)s.dev(1, 16, 8); // theta, lp, d/dloc sum, d/dtheta, min_eig, params_bar[5]
+    if (s.go()) return s.rc;
+    if (dfill) {
+        if (s.host_visible(dfill)) {
+            double* hf = reinterpret_cast<double*>(s.to_host(dfill));
+            for (int64_t i = 0; i < H * W; ++i) hf[i] = loc_scalar;
+        } else {
+            HIP_TRY(c, gpt_launch_fill(dfill, H * W, loc_scalar, c->stream));
+        }
+        dl = dfill;
+    }
+    s.put(dsc, theta);
+    if (s.rc) return s.rc;
+    s.arm(); // (taken up by the one-launch route for lattices that fit a workgroup, gpt_api_obs.hip)
+    if ((rc = gpt_gp_inv_rfft2_obs_lpdf_kernel_vjp(c, family, matern, nu, dz, 0, dl, 0, dpar, nugget, dob, 0, oh, ow,
+                                                   family == GPT_OBS_POISSON_LOG ? nullptr : dsc, prior, H, W, 1, dim1,
+                                                   dsc + 1, dgz, dsc + 2, params_bar ? dsc + 5 : nullptr, dsc + 3, dsc + 4)))
+        return rc;
+    s.down(grad_z, dgz, H, W, 8);
+    s.down(lp, dsc + 1, 1, 1, 8);
+    s.down(grad_loc_sum, dsc + 2, 1, 1, 8);
+    if (params_bar) s.down(params_bar, dsc + 5, 1, npar, 8);
+    if (family != GPT_OBS_POISSON_LOG) s.down(grad_theta, dsc + 3, 1, 1, 8);
+    else if (grad_theta) *grad_theta = 0.0;
+    return s.finish(dsc + 4);
+}
+
 int gpt_gp_rfft2_log_abs_det_jac_host(gpt_ctx* c, int layout, const double* cov, int64_t H, int64_t W, int dim1,
                                       double* out, double* grad_cov) {
     int rc = check_shape(c, H, W, 1, dim1);

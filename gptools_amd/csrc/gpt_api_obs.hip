@@ -69,6 +69,69 @@ int run_obs_fused(gpt_ctx* c, int family, const double* z, int64_t z_bs, const d
     return GPT_OK;
 }
 
+// Lattices that fit one workgroup's LDS: the whole density in ONE launch (gpt_small_obs.hip). cov != null: the spectrum
+// from memory; params != null: evaluated from the kernel parameters where needed (no cov, no d/dcov: params_bar).
+int small_obs_launch(gpt_ctx* c, bool armed, int family, const double* z, int64_t z_bs, const double* loc, int64_t loc_bs,
+                     const double* cov, int64_t cov_bs, const double* params, int matern, double nu, double nugget,
+                     const double* obs, int64_t obs_bs, int64_t oh, int64_t ow, const double* theta, int prior, int64_t H,
+                     int64_t W, int64_t batch, int dim1, double* lp, double* f_out, double* grad_z, double* grad_loc,
+                     double* grad_loc_sum, double* grad_cov, double* params_bar, double* grad_theta, double* min_eig) {
+    int rc;
+    LatArgs a = base_args(H, W, batch, dim1);
+    if ((rc = make_plan(c, a.W, a.pw, false)) != GPT_OK) return rc;
+    if ((rc = make_plan(c, a.H, a.ph, false)) != GPT_OK) return rc;
+    a.x = z; a.x_bs = z_bs;
+    a.cov = cov; a.cov_bs = cov_bs;
+    a.out = grad_z;
+    a.out_cov = grad_cov; // (may be null: the reverse mode then keeps d/dcov to itself, put_cbar)
+    a.zprior = prior ? 1 : 0;
+    a.min_eig = min_eig;
+    if (params) {
+        a.kpar = params;
+        a.kmatern = matern ? 1 : 0;
+        a.knu = nu;
+        a.kgamma = matern ? std::tgamma(nu + 1.0) / std::tgamma(nu) : 0.0; // fft2.stan:245
+        a.knugget = nugget;
+    }
+    SmallObsArgs o;
+    o.loc = loc; o.loc_bs = loc_bs;
+    o.obs = obs; o.obs_bs = obs_bs;
+    o.oh = (int)oh; o.ow = (int)ow; o.family = family;
+    o.theta = theta;
+    o.f_out = f_out;
+    o.grad_loc = grad_loc;
+    o.lp = lp;
+    o.grad_theta = grad_theta;
+    o.grad_loc_sum = grad_loc_sum;
+    o.kbar = params_bar;
+    unsigned long long* flag = nullptr;
+    if (armed && batch == 1 && c->done_dev) { // (the host entry point's request, gpt_ctx::done_*)
+        flag = c->done_dev;
+        c->done_published = true;
+        ++c->done_seq;
+    }
+    HIP_TRY(c, gpt_launch_small_obs(a, o, c->stream, flag, c->done_seq));
+    return GPT_OK;
+}
+
+int check_obs_args(gpt_ctx* c, int family, const void* z, const void* spec, const void* obs, const void* lp, const void* grad_z,
+                   const double* theta, int64_t oh, int64_t ow, int64_t H, int64_t W) {
+    if (!z || !spec || !obs || !lp || !grad_z)
+        return fail(c, GPT_ERR_SHAPE, "z, cov (or params), obs, lp and grad_z must not be null");
+    if (family != GPT_OBS_NORMAL && family != GPT_OBS_POISSON_LOG && family != GPT_OBS_NEG_BINOMIAL_2_LOG)
+        return fail(c, GPT_ERR_SHAPE, "unknown observation family");
+    if (family != GPT_OBS_POISSON_LOG && !theta) return fail(c, GPT_ERR_SHAPE, "this observation family needs theta");
+    if (oh < 1 || ow < 1 || oh > H || ow > W)
+        return fail(c, GPT_ERR_SHAPE, "the observed window must lie inside the lattice");
+    return GPT_OK;
+}
+
+// GPT_OBS_SMALL_FUSED=0: the composed route for lattices that fit a workgroup too (A/B timing)
+bool small_obs_enabled() {
+    static const bool off = [] { const char* e = getenv("GPT_OBS_SMALL_FUSED"); return e && e[0] == '0'; }();
+    return !off;
+}
+
 } // namespace
 
 extern "C" {
@@ -84,12 +147,7 @@ int gpt_gp_inv_rfft2_obs_lpdf_vjp(gpt_ctx* c, int family, const double* z, int64
                                   double* grad_loc_sum, double* grad_cov, double* grad_theta, double* min_eig) {
     int rc = check_shape(c, H, W, batch, dim1);
     if (rc) return rc;
-    if (!z || !cov || !obs || !lp || !grad_z) return fail(c, GPT_ERR_SHAPE, "z, cov, obs, lp and grad_z must not be null");
-    if (family != GPT_OBS_NORMAL && family != GPT_OBS_POISSON_LOG && family != GPT_OBS_NEG_BINOMIAL_2_LOG)
-        return fail(c, GPT_ERR_SHAPE, "unknown observation family");
-    if (family != GPT_OBS_POISSON_LOG && !theta) return fail(c, GPT_ERR_SHAPE, "this observation family needs theta");
-    if (oh < 1 || ow < 1 || oh > H || ow > W)
-        return fail(c, GPT_ERR_SHAPE, "the observed window must lie inside the lattice");
+    if ((rc = check_obs_args(c, family, z, cov, obs, lp, grad_z, theta, oh, ow, H, W))) return rc;
     // (a request of the host entry point to let the LAST launch publish its completion, gpt_ctx::done_*: only the
     // one-launch route below may take it up -- the composed route's first lattice launch must not)
     const bool armed = c->done_armed;
@@ -97,42 +155,10 @@ int gpt_gp_inv_rfft2_obs_lpdf_vjp(gpt_ctx* c, int family, const double* z, int64
     if (batch == 0) return GPT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const int64_t hw = H * W, hwf = H * (W / 2 + 1);
-    // Lattices that fit one workgroup's LDS (the docs models: 35 x 60, n = 100 ... 200): the whole density in ONE launch,
-    // the lattice never leaves LDS (gpt_small_obs.hip; GPT_OBS_SMALL_FUSED=0: the composed route, for A/B timing).
-    static const bool small_fused_off = [] { const char* e = getenv("GPT_OBS_SMALL_FUSED"); return e && e[0] == '0'; }();
-    if (!small_fused_off && path_for_shape(H, W) == 0) {
-        LatArgs a = base_args(H, W, batch, dim1);
-        if ((rc = make_plan(c, a.W, a.pw, false)) != GPT_OK) return rc;
-        if ((rc = make_plan(c, a.H, a.ph, false)) != GPT_OK) return rc;
-        a.x = z; a.x_bs = z_bs;
-        a.cov = cov; a.cov_bs = cov_bs;
-        a.out = grad_z;
-        a.out_cov = grad_cov;
-        if (!grad_cov) {
-            if ((rc = ensure(c, c->sink, c->sink_bytes, sizeof(double) * (size_t)batch * hwf))) return rc;
-            a.out_cov = c->sink;
-        }
-        a.zprior = prior ? 1 : 0;
-        a.min_eig = min_eig;
-        SmallObsArgs o;
-        o.loc = loc; o.loc_bs = loc_bs;
-        o.obs = obs; o.obs_bs = obs_bs;
-        o.oh = (int)oh; o.ow = (int)ow; o.family = family;
-        o.theta = theta;
-        o.f_out = f_out;
-        o.grad_loc = grad_loc;
-        o.lp = lp;
-        o.grad_theta = grad_theta;
-        o.grad_loc_sum = grad_loc_sum;
-        unsigned long long* flag = nullptr;
-        if (armed && batch == 1 && c->done_dev) {
-            flag = c->done_dev;
-            c->done_published = true;
-            ++c->done_seq;
-        }
-        HIP_TRY(c, gpt_launch_small_obs(a, o, c->stream, flag, c->done_seq));
-        return GPT_OK;
-    }
+    if (small_obs_enabled() && path_for_shape(H, W) == 0)
+        return small_obs_launch(c, armed, family, z, z_bs, loc, loc_bs, cov, cov_bs, nullptr, 0, 0.0, 0.0, obs, obs_bs, oh, ow, theta,
+                                prior, H, W, batch, dim1, lp, f_out, grad_z, grad_loc, grad_loc_sum, grad_cov, nullptr,
+                                grad_theta, min_eig);
     // GPT_OBS_FUSED=1 (read per call): one row kernel does inverse rows -> observation model -> forward rows in place
     // on the workspace. Same results; measured slower than the three composed steps on MI355X (200
     // VGPRs leave two waves per SIMD to hide the densities' dependent chains), so it is off unless asked for.
@@ -189,6 +215,70 @@ int gpt_gp_inv_rfft2_obs_lpdf_vjp(gpt_ctx* c, int family, const double* z, int64
             return rc;
         HIP_TRY(c, gpt_launch_obs_combine(sums, prior ? psum : nullptr, nb, lp + b0, grad_theta ? grad_theta + b0 : nullptr,
                                           grad_loc_sum ? grad_loc_sum + b0 : nullptr, nullptr, c->stream));
+    }
+    return GPT_OK;
+}
+
+// The same density with the spectrum given by its kernel parameters (the inverse-transform half:
+// fft2.stan:206-247 feeding fft2.stan:126-130): params [batch][5] = (sigma, length_scale[2], period[2]) ([batch][3] for
+// the 1-D functions), matern / nu / nugget as for gpt_gp_rfft2_lpdf_kernel_vjp; params_bar the reverse mode down to them.
+// trees.stan rebuilds gp_periodic_matern_cov_rfft2 on every gradient evaluation: behind the Stan interface that is three
+// calls (spectrum, density, the spectrum's reverse mode) and two H x (W/2+1) arrays each way; here one call and five
+// numbers. Lattices that fit a workgroup's LDS never hold the spectrum anywhere (gpt_small_obs.hip, KMODE); every other
+// shape composes the three calls on library-owned scratch, same results.
+int gpt_gp_inv_rfft2_obs_lpdf_kernel_vjp(gpt_ctx* c, int family, int matern, double nu, const double* z, int64_t z_bs,
+                                         const double* loc, int64_t loc_bs, const double* params, double nugget,
+                                         const double* obs, int64_t obs_bs, int64_t oh, int64_t ow, const double* theta,
+                                         int prior, int64_t H, int64_t W, int64_t batch, int dim1, double* lp,
+                                         double* grad_z, double* grad_loc_sum, double* params_bar, double* grad_theta,
+                                         double* min_eig) {
+    int rc = check_shape(c, H, W, batch, dim1);
+    if (rc) return rc;
+    if ((rc = check_obs_args(c, family, z, params, obs, lp, grad_z, theta, oh, ow, H, W))) return rc;
+    if (matern && !(nu > 0)) return fail(c, GPT_ERR_SHAPE, "nu must be positive");
+    const bool armed = c->done_armed;
+    c->done_armed = false;
+    if (batch == 0) return GPT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the in-kernel evaluation knows exp-quad and half-integer Matern smoothness (nu = 0.5, 1.5, ... 5.5), 2-D layout
+    const bool nu_ok = !matern || (nu <= 5.5 && nu - std::floor(nu) == 0.5 /* kern_eval */);
+    if (small_obs_enabled() && !dim1 && nu_ok && path_for_shape(H, W) == 0)
+        return small_obs_launch(c, armed, family, z, z_bs, loc, loc_bs, nullptr, 0, params, matern, nu, nugget, obs, obs_bs, oh, ow,
+                                theta, prior, H, W, batch, dim1, lp, nullptr, grad_z, nullptr, grad_loc_sum, nullptr, params_bar,
+                                grad_theta, min_eig);
+    // composed: cov and d/dcov live in scratch, a chunk of lattices at a time (as gpt_gp_rfft2_lpdf_kernel_vjp)
+    const size_t hwf = (size_t)H * (size_t)(W / 2 + 1);
+    int64_t chunk = (int64_t)((size_t)(128u << 20) / (hwf * sizeof(double)));
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    if ((rc = ensure(c, c->kscr, c->kscr_bytes, 2 * sizeof(double) * hwf * (size_t)chunk)) != GPT_OK) return rc;
+    double* cov = c->kscr;
+    double* dcov = c->kscr + hwf * (size_t)chunk;
+    const int npar = dim1 ? 3 : 5;
+    for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
+        const int64_t nb = batch - b0 < chunk ? batch - b0 : chunk;
+        ElemArgs e = elem_args(H, W, nb, dim1);
+        e.par = params + b0 * npar;
+        e.out = cov;
+        e.nu = nu;
+        e.gamma_ratio = matern ? std::tgamma(nu + (dim1 ? 0.5 : 1.0)) / std::tgamma(nu) : 0.0; // fft1.stan:173, fft2.stan:245
+        e.nugget = nugget;
+        if ((rc = run_elem(c, matern ? EL_MATERN : EL_EXPQUAD, e, false, 0, 0.0, nullptr, nullptr)) != GPT_OK) return rc;
+        if ((rc = gpt_gp_inv_rfft2_obs_lpdf_vjp(c, family, z + b0 * z_bs, z_bs, loc ? loc + b0 * loc_bs : nullptr, loc_bs, cov,
+                                                (int64_t)hwf, obs + b0 * obs_bs, obs_bs, oh, ow, theta ? theta + b0 : nullptr,
+                                                prior, H, W, nb, dim1, lp + b0, nullptr, grad_z + b0 * H * W, nullptr,
+                                                grad_loc_sum ? grad_loc_sum + b0 : nullptr, params_bar ? dcov : nullptr,
+                                                grad_theta ? grad_theta + b0 : nullptr, min_eig ? min_eig + b0 : nullptr)))
+            return rc;
+        if (params_bar) {
+            if (matern)
+                rc = gpt_gp_periodic_matern_cov_rfft2_vjp(c, nu, H, W, params + b0 * npar, dcov, (int64_t)hwf, nb, dim1,
+                                                          params_bar + b0 * npar);
+            else
+                rc = gpt_gp_periodic_exp_quad_cov_rfft2_vjp(c, H, W, params + b0 * npar, dcov, (int64_t)hwf, nb, dim1,
+                                                            params_bar + b0 * npar);
+            if (rc) return rc;
+        }
     }
     return GPT_OK;
 }

@@ -316,6 +316,9 @@ struct EwAcc {
     // OP_LPDF_KVJP: sums of cbar * ck, cbar * ck * f1, cbar * ck * f2 (ck = kernel part of c, f = its logarithmic
     // length-scale sensitivities, kern_eval): everything d/d(sigma, length_scale, period) needs
     double k0, k1, k2;
+    // OP_INV_VJP: d lp / d c of the entries the last elementwise call handled (put_cbar). The kernel-fused one-workgroup
+    // kernel (gpt_small_obs.hip) feeds it to acc_kern instead of reading d/dcov back; everywhere else it is dead code.
+    double cb;
 };
 
 __device__ __forceinline__ void acc_init(EwAcc& acc) {
@@ -324,6 +327,7 @@ __device__ __forceinline__ void acc_init(EwAcc& acc) {
     acc.mant = 1.0;
     acc.ex = 0;
     acc.k0 = acc.k1 = acc.k2 = 0.0;
+    acc.cb = 0.0;
 }
 // acc += log(c) for a pair entry, deferred.
 __device__ __forceinline__ void acc_log(EwAcc& acc, double c) {
@@ -394,6 +398,12 @@ __device__ __forceinline__ EwPtrs make_ptrs(const LatArgs& a, int64_t b) {
     P.kp.r1 = P.kp.r2 = P.kp.camp = P.kp.tn = P.kp.gco = 0.0;
     P.kp.m = 0;
     return P;
+}
+// d lp / d c of one spectrum entry out of the reverse mode of the inverse transform: stored (a null out_cov: the caller
+// has no use for the array -- the kernel-fused route, whose spectrum was never in memory) and left in acc.cb.
+__device__ __forceinline__ void put_cbar(const EwPtrs& P, EwAcc& acc, unsigned at, double v) {
+    if (P.out_cov) P.out_cov[at] = v;
+    acc.cb += v;
 }
 // Kernels that run the kernel-fused ops call this once after make_ptrs (workgroup-uniform control flow).
 template <int OP> __device__ __forceinline__ void kern_prepare(const LatArgs& a, EwPtrs& P) {
@@ -534,7 +544,7 @@ __device__ __forceinline__ cplx ew_interior_ic(const LatArgs& a, const ZLayout& 
         P.out[iz + L.im_col(j)] = fma(-pz, pi, k2 * s * F.y);
         acc.sum -= pz * 0.5 * fma(pr, pr, pi * pi);
         const double sbar = k2 * fma(pr, F.x, pi * F.y);
-        P.out_cov[ic] = sbar * s / (2.0 * c);
+        put_cbar(P, acc, ic, sbar * s / (2.0 * c));
     } else if (OP == OP_FWD_VJP) {
         // F = rfft2(y - loc); Q = pack(zbar); returns Dh = Q / (2 s)
         const double s = sqrt(0.5 * n * c);
@@ -650,7 +660,7 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
             P.out[zr] = fma(-pz, pr, k1 * s * FA.x);
             acc.sum -= pz * 0.5 * pr * pr;
             const double sbar = k1 * pr * FA.x;
-            P.out_cov[ck] = sbar * s / (2.0 * c);
+            put_cbar(P, acc, ck, sbar * s / (2.0 * c));
         } else {
             const double s = sqrt(0.5 * n * c), sm = sqrt(0.5 * n * cm);
             const double pr = P.x[zr], pi = P.x[zi];
@@ -658,8 +668,8 @@ __device__ __forceinline__ cplx ew_edge_c(const LatArgs& a, const ZLayout& L, co
             P.out[zi] = fma(-pz, pi, k1 * (s + sm) * FA.y);
             acc.sum -= pz * 0.5 * fma(pr, pr, pi * pi);
             const double sbar = k1 * fma(pr, FA.x, pi * FA.y);
-            P.out_cov[ck] = sbar * s / (2.0 * c);
-            P.out_cov[cm_] = sbar * sm / (2.0 * cm);
+            put_cbar(P, acc, ck, sbar * s / (2.0 * c));
+            put_cbar(P, acc, cm_, sbar * sm / (2.0 * cm));
         }
     } else if (OP == OP_FWD_VJP) {
         if (real_pt) {

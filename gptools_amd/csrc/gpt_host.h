@@ -137,7 +137,8 @@ hipError_t gpt_launch_obs_combine(const double* sums, const double* psum, int64_
                                   double* grad_loc_sum, double* nobs, hipStream_t st);
 hipError_t gpt_launch_fill(double* p, int64_t n, double v, hipStream_t st);
 // The same model density in ONE launch for lattices that fit a workgroup's LDS (gpt_small_obs.hip). `a` as for OP_INV_VJP
-// (x = z, cov, out = d/dz, out_cov = d/dcov -- never null --, zprior, min_eig), plans made; the rest here.
+// (x = z, cov, out = d/dz, out_cov = d/dcov, zprior, min_eig), plans made; the rest here. a.kpar set instead of a.cov:
+// the kernel-fused form (a.kmatern, a.knu, a.kgamma, a.knugget as for OP_LPDF_KVJP).
 struct SmallObsArgs {
     const double* loc; // [batch][H][W], loc_bs apart (0 = shared), or null (0 everywhere)
     int64_t loc_bs;
@@ -150,6 +151,7 @@ struct SmallObsArgs {
     double* lp;          // [batch]
     double* grad_theta;  // [batch] or null
     double* grad_loc_sum; // [batch] or null
+    double* kbar;         // a.kpar set (kernel-fused: no cov, a.out_cov null): [batch][5] d / d(sigma, length_scale, period), or null
 };
 hipError_t gpt_launch_small_obs(const LatArgs& a, const SmallObsArgs& o, hipStream_t st,
                                 unsigned long long* done_flag = nullptr, unsigned long long done_seq = 0);

@@ -25,6 +25,11 @@
 namespace {
 
 // `a` is set up as for OP_INV_VJP (x = z, cov, out = d/dz, out_cov = d/dcov, zprior); SmallObsArgs carries the rest.
+// KMODE 1 / 2 (SURVEY 8(f) rank 4 for the non-centred models: trees.stan rebuilds its spectrum from (sigma, length_scale)
+// on every gradient evaluation): no `cov` in memory at all -- the Matern / squared-exponential spectral density is
+// evaluated from a.kpar[b] (+ a.knugget) where an entry is needed, in both elementwise passes, and d lp / d c goes into
+// the three sums behind d / d(sigma, length_scale, period) instead of into an array (a.out_cov null, o.kbar).
+template <int KMODE>
 __global__ void __launch_bounds__(1024) small_obs_kernel(LatArgs a, SmallObsArgs o, int cap, int sS, SmallStages ss) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* red = reinterpret_cast<double*>(smem); // 5 x 16 doubles (GPT_SMALL_HDR bytes)
@@ -33,7 +38,8 @@ __global__ void __launch_bounds__(1024) small_obs_kernel(LatArgs a, SmallObsArgs
     const int64_t b = blockIdx.x;
     const int H = a.H, W = a.W;
     const ZLayout L = make_layout(a);
-    const EwPtrs P = make_ptrs(a, b);
+    EwPtrs P = make_ptrs(a, b);
+    if (KMODE) kern_prepare<KMODE == 1 ? OP_LPDF_KVJP : OP_LPDF_KVJP_EQ>(a, P);
     const int NC = 1 + L.wc, Hp = (H + 1) / 2;
     const bool weven = (W % 2) == 0;
     const unsigned mW = ss.mW, mNC = ss.mNC, mwc = ss.mwc;
@@ -56,7 +62,8 @@ __global__ void __launch_bounds__(1024) small_obs_kernel(LatArgs a, SmallObsArgs
         oth = t;
     };
     // cov of this thread's first entries: used by BOTH elementwise passes
-    const SmallCovPre pre = small_cov_prefetch(a.cov + b * a.cov_bs, L, H, W, mwc, weven);
+    SmallCovPre pre = {1.0, 1.0, 1.0, 1.0};
+    if (!KMODE) pre = small_cov_prefetch(a.cov + b * a.cov_bs, L, H, W, mwc, weven);
     // per-lattice constants of the observation family (a logarithm, lgamma and digamma of theta): under the transforms
     const double th = o.theta ? o.theta[b] : 0.0;
     double kf[3];
@@ -66,8 +73,8 @@ __global__ void __launch_bounds__(1024) small_obs_kernel(LatArgs a, SmallObsArgs
     {
         EwAcc acc1; // (its minimum is found again in step 5)
         acc_init(acc1);
-        small_interior<OP_GP_INV_RFFT2>(a, L, P, cur, sS, H, mwc, pre, acc1);
-        small_packed0<OP_GP_INV_RFFT2>(a, L, P, cur, sS, H, W, weven, pre, acc1);
+        small_interior<OP_GP_INV_RFFT2, KMODE>(a, L, P, cur, sS, H, mwc, pre, acc1);
+        small_packed0<OP_GP_INV_RFFT2, KMODE>(a, L, P, cur, sS, H, W, weven, pre, acc1);
     }
     __syncthreads();
     // 2. inverse transform: columns, merge of the row pairs, rows
@@ -122,28 +129,44 @@ __global__ void __launch_bounds__(1024) small_obs_kernel(LatArgs a, SmallObsArgs
     // 5. reverse mode of the inverse transform against z and cov (writes d/dz, d/dcov; the prior's share if asked for)
     EwAcc acc;
     acc_init(acc);
-    small_interior<OP_INV_VJP>(a, L, P, cur, sS, H, mwc, pre, acc);
-    small_packed0<OP_INV_VJP>(a, L, P, cur, sS, H, W, weven, pre, acc);
-    // 6. sums: wave by wave into LDS, the last thread adds them up
+    small_interior<OP_INV_VJP, KMODE>(a, L, P, cur, sS, H, mwc, pre, acc);
+    small_packed0<OP_INV_VJP, KMODE>(a, L, P, cur, sS, H, W, weven, pre, acc);
+    // 6. sums: wave by wave into LDS (8 x 16 slots = GPT_SMALL_HDR), the last thread adds them up
     {
         const int nw = ((int)blockDim.x + 63) >> 6, wv = (int)threadIdx.x >> 6;
         const double r0 = wave_sum(s0), r1 = wave_sum(s1), r2 = wave_sum(s2), r3 = wave_sum(acc.sum), r4 = wave_min(acc.mn);
+        double rk[3] = {0.0, 0.0, 0.0};
+        if (KMODE) {
+            rk[0] = wave_sum(acc.k0);
+            rk[1] = wave_sum(acc.k1);
+            rk[2] = wave_sum(acc.k2);
+        }
         if ((threadIdx.x & 63) == 0) {
             red[wv] = r0;
             red[16 + wv] = r1;
             red[32 + wv] = r2;
             red[48 + wv] = r3;
             red[64 + wv] = r4;
+            if (KMODE) {
+                red[80 + wv] = rk[0];
+                red[96 + wv] = rk[1];
+                red[112 + wv] = rk[2];
+            }
         }
         __syncthreads();
         if (threadIdx.x == blockDim.x - 1) {
-            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0, t4 = INFINITY;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0, t4 = INFINITY, tk[3] = {0.0, 0.0, 0.0};
             for (int i = 0; i < nw; ++i) {
                 t0 += red[i];
                 t1 += red[16 + i];
                 t2 += red[32 + i];
                 t3 += red[48 + i];
                 t4 = fmin(t4, red[64 + i]);
+                if (KMODE) {
+                    tk[0] += red[80 + i];
+                    tk[1] += red[96 + i];
+                    tk[2] += red[112 + i];
+                }
             }
             // z ~ std_normal(): the elementwise stage summed -z^2 / 2 (a.zprior), the constant goes on here
             const double prior = a.zprior ? t3 - 0.5 * n * 1.8378770664093454836 : 0.0;
@@ -151,6 +174,15 @@ __global__ void __launch_bounds__(1024) small_obs_kernel(LatArgs a, SmallObsArgs
             if (o.grad_theta) o.grad_theta[b] = t1;
             if (o.grad_loc_sum) o.grad_loc_sum[b] = t2;
             if (a.min_eig) a.min_eig[b] = t4;
+            if (KMODE && o.kbar) { // (as finalize_block, gpt_common.h)
+                const double* par = a.kpar + 5 * b;
+                double* kb = o.kbar + 5 * b;
+                kb[0] = 2.0 * tk[0] / par[0];      // sigma
+                kb[1] = (tk[0] - tk[1]) / par[1];  // length_scale[0]
+                kb[2] = (tk[0] - tk[2]) / par[2];  // length_scale[1]
+                kb[3] = (tk[1] - tk[0]) / par[3];  // period[0]
+                kb[4] = (tk[2] - tk[0]) / par[4];  // period[1]
+            }
         }
     }
     if (ss.done_flag) { // (uniform; one workgroup: batch == 1 -- see gpt_small.hip)
@@ -176,11 +208,16 @@ hipError_t gpt_launch_small_obs(const LatArgs& a, const SmallObsArgs& o, hipStre
     if (e != hipSuccess) return e;
     const uint64_t bit = dev < 64 ? (uint64_t)1 << dev : 0;
     if (lds > 64 * 1024 && !(attr_set.load(std::memory_order_relaxed) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_obs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
-        if (e != hipSuccess) return e;
+        for (const void* k : {reinterpret_cast<const void*>(&small_obs_kernel<0>), reinterpret_cast<const void*>(&small_obs_kernel<1>),
+                              reinterpret_cast<const void*>(&small_obs_kernel<2>)}) {
+            e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
         attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(small_obs_kernel, dim3((unsigned)a.batch), dim3(nthreads), lds, st, a, o, cap, sS, ss);
+    const dim3 grid((unsigned)a.batch), block(nthreads);
+    if (!a.kpar) hipLaunchKernelGGL(small_obs_kernel<0>, grid, block, lds, st, a, o, cap, sS, ss);
+    else if (a.kmatern) hipLaunchKernelGGL(small_obs_kernel<1>, grid, block, lds, st, a, o, cap, sS, ss);
+    else hipLaunchKernelGGL(small_obs_kernel<2>, grid, block, lds, st, a, o, cap, sS, ss);
     return hipGetLastError();
 }

@@ -115,18 +115,28 @@ __device__ __forceinline__ SmallCovPre small_cov_prefetch(const double* cov_b, c
 }
 
 // Elementwise stage on the interior columns 1..wc of the packed spectrum at `S` (in place for the ops with an inverse).
-template <int OP>
+// KMODE: where the spectrum comes from -- 0: `cov` in memory; 1 / 2: the Matern / squared-exponential kernel evaluated
+// here from the lattice's parameters (kern_eval on P.kp, + a.knugget; gpt_small_obs.hip), and for OP_INV_VJP the three
+// sums behind d / d(sigma, length_scale, period) accumulated from each entry's d lp / d c (acc.cb, put_cbar).
+template <int OP, int KMODE = 0>
 __device__ __forceinline__ void small_interior(const LatArgs& a, const ZLayout& L, const EwPtrs& P, LdsLine S, int sS, int H,
                                                unsigned mwc, const SmallCovPre& pre, EwAcc& acc) {
     for (int w = threadIdx.x; w < H * L.wc; w += blockDim.x) {
         const int i = (int)fastdiv((unsigned)w, (unsigned)L.wc, mwc), j = 1 + (w - i * L.wc);
         const cplx F = S[i * sS + j];
         double c = 1.0;
-        if (small_uses_cov<OP>())
+        KernVal kv = {0.0, 0.0, 0.0};
+        if (KMODE) {
+            kv = kern_eval<KMODE == 1>(a, P.kp, i, j);
+            c = kv.ck + a.knugget;
+            acc.cb = 0.0;
+        } else if (small_uses_cov<OP>()) {
             c = (w == (int)threadIdx.x) ? pre.ci
                                         : (w == (int)(threadIdx.x + blockDim.x)) ? pre.ci1
                                                                                  : P.cov[(unsigned)i * (unsigned)L.Wf + (unsigned)j];
+        }
         const cplx G = ew_interior_c<OP>(a, L, P, i, j, F, c, acc);
+        if (KMODE && OP == OP_INV_VJP) acc_kern(acc, kv, acc.cb);
         if (op_has_inv(OP)) S[i * sS + j] = G;
         acc_renorm(acc);
     }
@@ -137,7 +147,7 @@ __device__ __forceinline__ void small_interior(const LatArgs& a, const ZLayout& 
 // that the two divisions and logarithms of a row run side by side, and on the LAST threads of the workgroup, whose
 // waves have the fewest interior entries (the two loops then overlap instead of queueing up on the first wave).
 // Lane pairs (t, t ^ 1) swap their results through DPP.
-template <int OP>
+template <int OP, int KMODE = 0>
 __device__ __forceinline__ void small_packed0(const LatArgs& a, const ZLayout& L, const EwPtrs& P, LdsLine S, int sS, int H,
                                               int W, bool weven, const SmallCovPre& pre, EwAcc& acc) {
     const int tail = (int)blockDim.x - 1 - (int)threadIdx.x; // work item: (row k, edge column)
@@ -150,11 +160,17 @@ __device__ __forceinline__ void small_packed0(const LatArgs& a, const ZLayout& L
         if (e == 0 || weven) {
             const int j = e ? W / 2 : 0;
             double c = 1.0, cm = 1.0;
-            if (small_uses_cov<OP>()) {
+            KernVal kv = {0.0, 0.0, 0.0};
+            if (KMODE) { // (rows are mirrored in the kernel: row H - k has the value of row k)
+                kv = kern_eval<KMODE == 1>(a, P.kp, k, j);
+                c = cm = kv.ck + a.knugget;
+                acc.cb = 0.0;
+            } else if (small_uses_cov<OP>()) {
                 c = (t == tail) ? pre.c : P.cov[(unsigned)k * (unsigned)L.Wf + (unsigned)j];
                 cm = (t == tail) ? pre.cm : P.cov[(unsigned)km * (unsigned)L.Wf + (unsigned)j];
             }
             V = ew_edge_c<OP>(a, L, P, k, j, V, c, cm, acc);
+            if (KMODE && OP == OP_INV_VJP) acc_kern(acc, kv, acc.cb);
         } else {
             V = make_double2(0.0, 0.0);
         }

@@ -573,6 +573,53 @@ def gp_rfft_lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugge
     return _lpdf_kernel_vjp(y, loc, kind, nu, sigma, length_scale, period, nugget, True, check)
 
 
+def _obs_lpdf_kernel_vjp(family, z, loc, kind, nu, sigma, length_scale, period, nugget, obs, theta, prior, dim1, check):
+    g = _prep(z, loc, None, dim1)
+    core = 1 if dim1 else 2
+    par, pshape = _params(dim1, sigma, length_scale, period, g["main"].device)
+    if pshape != g["bshape"]:
+        par = par.expand(*g["bshape"], par.shape[-1]).contiguous()
+    obs = _dev(obs, g["main"])
+    obs, _, o_bs = _batched(obs, core, g["bshape"])
+    oh = 1 if dim1 else obs.shape[-2]
+    ow = obs.shape[-1]
+    fam = OBS_FAMILIES[family]
+    th = None
+    if fam != 1:
+        if theta is None:
+            raise ValueError(f"the {family} family needs theta")
+        th = _dev(theta, g["main"]).expand(g["bshape"]).contiguous()
+        if not bool(((th > 0) & torch.isfinite(th)).all()):
+            raise ValueError(("Scale" if fam == 0 else "Precision") + " parameter must be positive finite")
+    lp, mn, gls = _new(g), _new(g), _new(g)
+    gth = _new(g) if th is not None else None
+    gz = torch.empty_like(g["main"])
+    pbar = torch.empty_like(par)
+    get_context(lp.device).call("gpt_gp_inv_rfft2_obs_lpdf_kernel_vjp", fam, int(kind != "expquad"), float(nu),
+                                _p(g["main"]), g["m_bs"], _p(g["loc"]), g["l_bs"], _p(par), float(nugget), _p(obs), o_bs, oh,
+                                ow, _p(th), int(bool(prior)), g["H"], g["W"], g["B"], g["dim1"], _p(lp), _p(gz), _p(gls),
+                                _p(pbar), _p(gth), _p(mn))
+    _check_pd(mn, check)
+    kbar = (pbar[..., 0], pbar[..., 1], pbar[..., 2]) if dim1 else (pbar[..., 0], pbar[..., 1:3], pbar[..., 3:5])
+    return dict(lp=lp, grad_z=gz, grad_loc_sum=gls, grad_kernel=kbar, grad_theta=gth)
+
+
+def gp_inv_rfft2_obs_lpdf_kernel_vjp(family, z, loc, kind, nu, sigma, length_scale, period, obs, theta=None, nugget=0.0,
+                                     prior=True, check=True):
+    """The non-centred model density of :func:`gp_inv_rfft2_obs_lpdf_vjp` with the spectrum given by its kernel
+    (fft2.stan:206-247 + ``nugget``, as docs/trees/trees.stan:26-29 builds it on every gradient evaluation) instead of
+    an array: one call, and gradients down to ``(sigma, length_scale[2], period[2])``. ``kind``: ``"expquad"`` or
+    ``"matern"`` (``nu``). Returns a dict: ``lp, grad_z, grad_loc_sum, grad_kernel = (d/dsigma, d/dlength_scale,
+    d/dperiod), grad_theta``. Lattices that fit one workgroup never hold the spectrum anywhere."""
+    return _obs_lpdf_kernel_vjp(family, z, loc, kind, nu, sigma, length_scale, period, nugget, obs, theta, prior, False, check)
+
+
+def gp_inv_rfft_obs_lpdf_kernel_vjp(family, z, loc, kind, nu, sigma, length_scale, period, obs, theta=None, nugget=0.0,
+                                    prior=True, check=True):
+    """1-D sibling (fft1.stan:154-176 feeding fft1.stan:67-70; padded.stan, poisson_regression_fourier_non_centered.stan)."""
+    return _obs_lpdf_kernel_vjp(family, z, loc, kind, nu, sigma, length_scale, period, nugget, obs, theta, prior, True, check)
+
+
 def _spec(kind, nu, height, width, sigma, length_scale, period, dim1):
     par, bshape = _params(dim1, sigma, length_scale, period)
     Wf = width // 2 + 1

@@ -13,3 +13,14 @@
 // prior: 1 adds std_normal_lpdf(to_vector(z)). All normalising constants are kept.
 real gp_inv_rfft2_obs_lpdf(matrix z, int family, matrix obs, real loc, matrix cov_rfft2, real theta, int prior);
 real gp_inv_rfft_obs_lpdf(vector z, int family, vector obs, real loc, vector cov_rfft, real theta, int prior);
+
+// The same with the spectrum given by its kernel instead of an array -- what docs/trees/trees.stan:26-29 computes first:
+//     rfft2_cov = gp_periodic_matern_cov_rfft2(1.5, H, W, sigma, [length_scale, length_scale]', [H, W]') + epsilon
+// -- so that one call replaces the spectrum, the density and (in reverse mode) the spectrum's adjoint, and five numbers
+// travel where two H x (W/2+1) matrices did:
+//     target += gp_inv_rfft2_obs_matern_lpdf(z | 2, to_matrix(frequency), loc, 1.5, sigma, ls, per, epsilon, 1 / kappa, 1);
+// nu is data (a literal in every reference model). *_exp_quad_*: the squared-exponential kernel of fft2.stan:206-213.
+real gp_inv_rfft2_obs_matern_lpdf(matrix z, int family, matrix obs, real loc, real nu, real sigma, vector length_scale,
+                                  vector period, real nugget, real theta, int prior);
+real gp_inv_rfft2_obs_exp_quad_lpdf(matrix z, int family, matrix obs, real loc, real sigma, vector length_scale, vector period,
+                                    real nugget, real theta, int prior);

@@ -260,6 +260,20 @@ int gpt_gp_inv_rfft2_obs_lpdf_vjp(gpt_ctx*, int family, const double* z, int64_t
                                   int64_t batch, int dim1, double* lp, double* f_out, double* grad_z, double* grad_loc,
                                   double* grad_loc_sum, double* grad_cov, double* grad_theta, double* min_eig);
 
+/* The same density with the spectrum given by its kernel parameters instead of an array: SURVEY 8(f) rank 4 for the
+ * non-centred models (fft2.stan:206-213 / :228-247 feeding fft2.stan:126-130; docs/trees/trees.stan:26-29 rebuilds
+ * gp_periodic_matern_cov_rfft2(1.5, ...) + a nugget on every gradient evaluation). params: [batch][5] = (sigma,
+ * length_scale[0..1], period[0..1]) ([batch][3] = (sigma, length_scale, period) when dim1); matern != 0: Matern with
+ * smoothness nu, else squared exponential; nugget is added to every entry. params_bar: [batch][5] (or [3]) d lp / d params,
+ * may be NULL. Lattices that fit one workgroup's LDS never hold the spectrum anywhere; other shapes compose the spectrum,
+ * gpt_gp_inv_rfft2_obs_lpdf_vjp and the spectrum's reverse mode on library-owned scratch. */
+int gpt_gp_inv_rfft2_obs_lpdf_kernel_vjp(gpt_ctx*, int family, int matern, double nu, const double* z, int64_t z_bs,
+                                         const double* loc, int64_t loc_bs, const double* params, double nugget,
+                                         const double* obs, int64_t obs_bs, int64_t obs_h, int64_t obs_w,
+                                         const double* theta, int prior, int64_t height, int64_t width, int64_t batch,
+                                         int dim1, double* lp, double* grad_z, double* grad_loc_sum, double* params_bar,
+                                         double* grad_theta, double* min_eig);
+
 /* ---- host-pointer entry points (what the Stan user header binds) ----------------
  * One lattice per call (batch == 1), `layout` as above. Matrices are height x width (cov: height x
  * (width/2+1)). */
@@ -288,6 +302,16 @@ int gpt_gp_inv_rfft2_obs_lpdf_host(gpt_ctx*, int layout, int family, const doubl
                                    int64_t obs_w, double theta, int prior, int64_t height, int64_t width, int dim1,
                                    double* lp, double* grad_z, double* grad_loc_sum /* may be NULL */,
                                    double* grad_cov /* may be NULL */, double* grad_theta /* may be NULL */);
+/* Host-pointer form of gpt_gp_inv_rfft2_obs_lpdf_kernel_vjp for one lattice: the whole right-hand side of
+ * docs/trees/trees.stan:26-49 (spectrum from the kernel parameters, field, masked counts, white-noise prior) in one call.
+ * params: (sigma, length_scale[0..1], period[0..1]), or (sigma, length_scale, period) when dim1; params_bar likewise, may
+ * be NULL. Errors as gpt_gp_inv_rfft2_obs_lpdf_host. */
+int gpt_gp_inv_rfft2_obs_lpdf_kernel_host(gpt_ctx*, int layout, int family, int matern, double nu, const double* z,
+                                          const double* loc, double loc_scalar, const double* params, double nugget,
+                                          const double* obs, int64_t obs_h, int64_t obs_w, double theta, int prior,
+                                          int64_t height, int64_t width, int dim1, double* lp, double* grad_z,
+                                          double* grad_loc_sum /* may be NULL */, double* params_bar /* may be NULL */,
+                                          double* grad_theta /* may be NULL */);
 /* Real-FFT layer and layout helpers on host pointers (values only; the reference uses them in tests and
  * generated quantities): rfft/rfft2 (util.stan:263,302), inv_rfft/inv_rfft2 (util.stan:291,315),
  * expand_rfft (util.stan:271), gp_evaluate_rfft(2)_scale, gp_unpack_rfft(2), gp_pack_rfft(2). */

@@ -492,6 +492,74 @@ stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T2__), T3__, GPT_BASE(T4__), T5__>
     return gptools_hip_stan::obs_lpdf<1>(z, family, obs, loc, cov_rfft, theta, prior, 1, "gp_inv_rfft_obs_lpdf");
 }
 
+// ... and with the spectrum given by its kernel (gptools/fft_obs.stan: gp_inv_rfft2_obs_matern_lpdf,
+// gp_inv_rfft2_obs_exp_quad_lpdf): gpt_gp_inv_rfft2_obs_lpdf_kernel_host, five parameters up and their five adjoints back.
+namespace gptools_hip_stan {
+template <bool MATERN, typename T0, typename TOBS, typename TLOC, typename TS, typename TL, typename TP, typename TTH>
+inline stan::return_type_t<T0, TLOC, TS, TL, TP, TTH> obs_kernel_lpdf(const T0& z, int family, const TOBS& obs, const TLOC& loc,
+                                                                      double nu, const TS& sigma, const TL& length_scale,
+                                                                      const TP& period, double nugget, const TTH& theta,
+                                                                      int prior, const char* fn) {
+    using stan::math::value_of;
+    const Mat<double, -1> zv = real_val<-1>(z), ov = real_val<-1>(obs);
+    const b::Shape s{zv.rows(), zv.cols(), 0};
+    const int64_t oh = ov.rows(), ow = ov.cols();
+    b::require_sizes(length_scale.size() == 2 && period.size() == 2 && oh >= 1 && ow >= 1 && oh <= s.H && ow <= s.W, fn);
+    auto ls = stan::math::to_arena(length_scale);
+    auto pd = stan::math::to_arena(period);
+    const double par[5] = {value_of(sigma), value_of(ls.coeff(0)), value_of(ls.coeff(1)), value_of(pd.coeff(0)),
+                           value_of(pd.coeff(1))};
+    b::ObsGrad og{0.0, 0.0};
+    stan::math::arena_t<Mat<double, -1>> gz(zv.rows(), zv.cols());
+    stan::math::arena_t<Eigen::Matrix<double, 5, 1>> pbar;
+    pbar.setZero();
+    const double value = b::obs_kernel_lpdf(family, MATERN, nu, zv.data(), value_of(loc), par, nugget, ov.data(), oh, ow,
+                                            value_of(theta), prior, s, gz.data(), pbar.data(), &og);
+    if constexpr (!any_var_v<T0, TLOC, TS, TL, TP, TTH>) {
+        return value;
+    } else {
+        auto az = stan::math::to_arena(z);
+        return stan::math::make_callback_var(value, [az, loc, sigma, ls, pd, theta, gz, pbar, og](auto& vi) mutable {
+            if constexpr (is_var_v<T0>) az.adj() += vi.adj() * gz;
+            add_adj(loc, vi.adj() * og.loc_sum);
+            add_adj(theta, vi.adj() * og.theta);
+            add_adj(sigma, vi.adj() * pbar.coeff(0));
+            if constexpr (is_var_v<TL>) {
+                ls.adj().coeffRef(0) += vi.adj() * pbar.coeff(1);
+                ls.adj().coeffRef(1) += vi.adj() * pbar.coeff(2);
+            }
+            if constexpr (is_var_v<TP>) {
+                pd.adj().coeffRef(0) += vi.adj() * pbar.coeff(3);
+                pd.adj().coeffRef(1) += vi.adj() * pbar.coeff(4);
+            }
+        });
+    }
+}
+}  // namespace gptools_hip_stan
+template <bool propto__, typename T0__, typename T2__, typename T3__, typename T4__, typename T5__, typename T6__, typename T7__,
+          typename T8__, typename T9__,
+          stan::require_all_t<GPT_REQ_MAT(T0__), GPT_REQ_MAT(T2__), stan::is_stan_scalar<T3__>, stan::is_stan_scalar<T4__>,
+                              stan::is_stan_scalar<T5__>, GPT_REQ_VEC(T6__), GPT_REQ_VEC(T7__), stan::is_stan_scalar<T8__>,
+                              stan::is_stan_scalar<T9__>>* = nullptr>
+stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T2__), T3__, T4__, T5__, stan::promote_args_t<GPT_BASE(T6__), GPT_BASE(T7__), T8__, T9__>>
+gp_inv_rfft2_obs_matern_lpdf(const T0__& z, const int& family, const T2__& obs, const T3__& loc, const T4__& nu, const T5__& sigma,
+                             const T6__& length_scale, const T7__& period, const T8__& nugget, const T9__& theta,
+                             const int& prior, std::ostream* pstream__) {
+    return gptools_hip_stan::obs_kernel_lpdf<true>(z, family, obs, loc, stan::math::value_of(nu), sigma, length_scale, period,
+                                                   stan::math::value_of(nugget), theta, prior, "gp_inv_rfft2_obs_matern_lpdf");
+}
+template <bool propto__, typename T0__, typename T2__, typename T3__, typename T4__, typename T5__, typename T6__, typename T7__,
+          typename T8__,
+          stan::require_all_t<GPT_REQ_MAT(T0__), GPT_REQ_MAT(T2__), stan::is_stan_scalar<T3__>, stan::is_stan_scalar<T4__>,
+                              GPT_REQ_VEC(T5__), GPT_REQ_VEC(T6__), stan::is_stan_scalar<T7__>, stan::is_stan_scalar<T8__>>* = nullptr>
+stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T2__), T3__, T4__, GPT_BASE(T5__), stan::promote_args_t<GPT_BASE(T6__), T7__, T8__>>
+gp_inv_rfft2_obs_exp_quad_lpdf(const T0__& z, const int& family, const T2__& obs, const T3__& loc, const T4__& sigma,
+                               const T5__& length_scale, const T6__& period, const T7__& nugget, const T8__& theta,
+                               const int& prior, std::ostream* pstream__) {
+    return gptools_hip_stan::obs_kernel_lpdf<false>(z, family, obs, loc, 0.0, sigma, length_scale, period,
+                                                    stan::math::value_of(nugget), theta, prior, "gp_inv_rfft2_obs_exp_quad_lpdf");
+}
+
 #undef GPT_REQ_VEC
 #undef GPT_REQ_CVEC
 #undef GPT_REQ_MAT

@@ -249,5 +249,18 @@ inline double obs_lpdf(int family, const double* z, double loc, const double* co
     return value;
 }
 
+// ... and with the spectrum given by its kernel parameters (gpt_gp_inv_rfft2_obs_lpdf_kernel_host): par / pbar as for
+// spectrum(); pbar may be null.
+inline double obs_kernel_lpdf(int family, bool matern, double nu, const double* z, double loc, const double* par, double nugget,
+                              const double* obs, int64_t oh, int64_t ow, double theta, int prior, Shape s, double* grad_z,
+                              double* pbar, ObsGrad* g) {
+    double value = 0.0, gls = 0.0, gth = 0.0;
+    check(gpt_gp_inv_rfft2_obs_lpdf_kernel_host(ctx(), GPT_COL_MAJOR, family, matern ? 1 : 0, nu, z, nullptr, loc, par, nugget, obs,
+                                                oh, ow, theta, prior, s.H, s.W, s.dim1, &value, grad_z, &gls, pbar, &gth),
+          s.dim1 ? "gp_inv_rfft_obs_kernel_lpdf" : "gp_inv_rfft2_obs_kernel_lpdf");
+    if (g) *g = ObsGrad{gls, gth};
+    return value;
+}
+
 } // namespace gptools_hip
 #endif // GPTOOLS_HIP_BIND_HPP

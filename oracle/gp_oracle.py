@@ -681,3 +681,38 @@ def gp_inv_rfft_obs_lpdf_vjp(family, z, loc, cov_rfft, obs, theta=None, prior=Tr
         lp = lp + std_normal_lpdf(z, (-1,))
         zbar = zbar - z
     return lp, f, zbar, locbar, locbar.sum(axis=-1), cbar, thbar
+
+
+def gp_inv_rfft2_obs_lpdf_kernel_vjp(family, z, loc, kind, nu, sigma, length_scale, period, obs, theta=None, nugget=0.0,
+                                     prior=True):
+    """The non-centred model density with the spectrum built from its kernel, as docs/trees/trees.stan:26-29 does on
+    every gradient evaluation: ``cov = kernel(sigma, length_scale, period) + nugget`` (fft2.stan:206-213 / :228-247), then
+    :func:`gp_inv_rfft2_obs_lpdf_vjp`, then the kernel's reverse mode. Returns
+    ``(lp, zbar, locbar_sum, (sigma_bar, length_scale_bar, period_bar), thetabar)``."""
+    h, w = np.asarray(z).shape[-2:]
+    if kind == "expquad":
+        cov = gp_periodic_exp_quad_cov_rfft2(h, w, sigma, length_scale, period) + nugget
+    else:
+        cov = gp_periodic_matern_cov_rfft2(nu, h, w, sigma, length_scale, period) + nugget
+    lp, _, zbar, _, lsum, cbar, thbar = gp_inv_rfft2_obs_lpdf_vjp(family, z, loc, cov, obs, theta, prior)
+    if kind == "expquad":
+        kbar = gp_periodic_exp_quad_cov_rfft2_vjp(h, w, sigma, length_scale, period, cbar)
+    else:
+        kbar = gp_periodic_matern_cov_rfft2_vjp(nu, h, w, sigma, length_scale, period, cbar)
+    return lp, zbar, lsum, kbar, thbar
+
+
+def gp_inv_rfft_obs_lpdf_kernel_vjp(family, z, loc, kind, nu, sigma, length_scale, period, obs, theta=None, nugget=0.0,
+                                    prior=True):
+    """1-D sibling (fft1.stan:154-176 feeding fft1.stan:67-70)."""
+    n = np.asarray(z).shape[-1]
+    if kind == "expquad":
+        cov = gp_periodic_exp_quad_cov_rfft(n, sigma, length_scale, period) + nugget
+    else:
+        cov = gp_periodic_matern_cov_rfft(nu, n, sigma, length_scale, period) + nugget
+    lp, _, zbar, _, lsum, cbar, thbar = gp_inv_rfft_obs_lpdf_vjp(family, z, loc, cov, obs, theta, prior)
+    if kind == "expquad":
+        kbar = gp_periodic_exp_quad_cov_rfft_vjp(n, sigma, length_scale, period, cbar)
+    else:
+        kbar = gp_periodic_matern_cov_rfft_vjp(nu, n, sigma, length_scale, period, cbar)
+    return lp, zbar, lsum, kbar, thbar

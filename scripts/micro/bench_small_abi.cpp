@@ -144,9 +144,55 @@ int main() {
             for (int i = 0; i < 500; ++i) host_call();
             us_host = 1e6 * (now() - t0) / 500;
         }
+        // ... and from the kernel parameters (Matern 3/2 + nugget, trees.stan:26-29): one call instead of spectrum + density +
+        // the spectrum's reverse mode
+        std::vector<double> par(batch * 5);
+        for (int64_t q = 0; q < batch; ++q) { par[5 * q] = 1.1; par[5 * q + 1] = 2.5; par[5 * q + 2] = 3.0; par[5 * q + 3] = (double)H; par[5 * q + 4] = (double)W; }
+        double *dpar, *dkb;
+        CK(hipMalloc(&dpar, par.size() * 8)); CK(hipMalloc(&dkb, par.size() * 8));
+        CK(hipMemcpy(dpar, par.data(), par.size() * 8, hipMemcpyHostToDevice));
+        auto kcall = [&] {
+            GK(gpt_gp_inv_rfft2_obs_lpdf_kernel_vjp(ctx, GPT_OBS_NEG_BINOMIAL_2_LOG, 1, 1.5, dz, n, dloc, 0, dpar, 1e-9, dob, 0, oh, ow, dth, 1,
+                                                    H, W, batch, 0, dlp, dgz, dgl, dkb, dgt, dmn));
+        };
+        for (int i = 0; i < 20; ++i) kcall();
+        CK(hipStreamSynchronize(st));
+        t0 = now();
+        for (int i = 0; i < it; ++i) kcall();
+        CK(hipStreamSynchronize(st));
+        const double us_kdev = 1e6 * (now() - t0) / it;
+        double us_khost = -1.0, us_3host = -1.0;
+        if (batch == 1) {
+            double lp, gt, gl, kb[5];
+            std::vector<double> gz(n), gc(H * Wf), cv(H * Wf);
+            auto khost = [&] {
+                const int rc = gpt_gp_inv_rfft2_obs_lpdf_kernel_host(ctx, GPT_COL_MAJOR, GPT_OBS_NEG_BINOMIAL_2_LOG, 1, 1.5, z.data(), nullptr, 0.5,
+                                                                     par.data(), 1e-9, obs.data(), oh, ow, 1.7, 1, H, W, 0, &lp, gz.data(), &gl, kb, &gt);
+                if (rc != GPT_OK) { printf("host call -> %d: %s\n", rc, gpt_last_error(ctx)); exit(1); }
+            };
+            for (int i = 0; i < 20; ++i) khost();
+            t0 = now();
+            for (int i = 0; i < 500; ++i) khost();
+            us_khost = 1e6 * (now() - t0) / 500;
+            // what the array interface costs a Stan model per gradient evaluation: three host calls
+            auto three = [&] {
+                GK(gpt_gp_periodic_matern_cov_rfft2_host(ctx, GPT_COL_MAJOR, 1.5, H, W, par.data(), 0, cv.data()));
+                for (auto& v : cv) v += 1e-9;
+                GK(gpt_gp_inv_rfft2_obs_lpdf_host(ctx, GPT_COL_MAJOR, GPT_OBS_NEG_BINOMIAL_2_LOG, z.data(), nullptr, 0.5, cv.data(), obs.data(), oh, ow,
+                                                  1.7, 1, H, W, 0, &lp, gz.data(), &gl, gc.data(), &gt));
+                GK(gpt_gp_periodic_matern_cov_rfft2_vjp_host(ctx, GPT_COL_MAJOR, 1.5, H, W, par.data(), gc.data(), 0, kb));
+            };
+            for (int i = 0; i < 20; ++i) three();
+            t0 = now();
+            for (int i = 0; i < 500; ++i) three();
+            us_3host = 1e6 * (now() - t0) / 500;
+        }
+        CK(hipFree(dpar)); CK(hipFree(dkb));
         printf("{\"case\": \"trees model density: 35x60, 25x50 negative-binomial counts, %lld chain(s) per launch\", "
-               "\"us_per_call_device_ptr\": %.2f, \"evals_per_s_device_ptr\": %.0f, \"us_per_call_host_ptr_col_major\": %.2f}\n",
-               (long long)batch, us_dev, batch / (1e-6 * us_dev), us_host);
+               "\"us_per_call_device_ptr\": %.2f, \"evals_per_s_device_ptr\": %.0f, \"us_per_call_host_ptr_col_major\": %.2f, "
+               "\"from_kernel_parameters\": {\"us_per_call_device_ptr\": %.2f, \"evals_per_s_device_ptr\": %.0f, "
+               "\"us_per_call_host_ptr_col_major\": %.2f, \"us_three_host_calls_array_interface\": %.2f}}\n",
+               (long long)batch, us_dev, batch / (1e-6 * us_dev), us_host, us_kdev, batch / (1e-6 * us_kdev), us_khost, us_3host);
         fflush(stdout);
         CK(hipFree(dz)); CK(hipFree(dc)); CK(hipFree(dob)); CK(hipFree(dth)); CK(hipFree(dlp)); CK(hipFree(dgz)); CK(hipFree(dgc));
         CK(hipFree(dgt)); CK(hipFree(dgl)); CK(hipFree(dmn)); CK(hipFree(dloc));

@@ -134,6 +134,15 @@ static void run_case(int64_t H, int64_t W, int dim1, uint64_t seed) {
         put(tag + "obs_grad_cov", cb);
         const double gg[2] = {og.loc_sum, og.theta};
         put(tag + "obs_grad_loc_theta", gg, 2);
+        // ... the same with the spectrum given by its Matern-3/2 parameters + a nugget (trees.stan:26-29)
+        double kb[5];
+        v = g::obs_kernel_lpdf(GPT_OBS_NEG_BINOMIAL_2_LOG, true, 1.5, z.data(), 0.35, par2, 1e-4, obs.data(), oh, ow, 2.5, 1, s,
+                               abar.data(), kb, &og);
+        put(tag + "obsk_lpdf", &v, 1);
+        put(tag + "obsk_grad_z", abar);
+        put(tag + "obsk_grad_par", kb, 5);
+        const double gk[2] = {og.loc_sum, og.theta};
+        put(tag + "obsk_grad_loc_theta", gk, 2);
     }
 }
 

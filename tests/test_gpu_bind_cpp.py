@@ -204,6 +204,16 @@ def test_bind_functions_vs_oracle(records, case):
         close(R("obs_grad_z", W), zbar, "obs d/dz")
         close(R("obs_grad_cov", wf), cbar, "obs d/dcov")
         close(records[tag + "obs_grad_loc_theta"], [lsum, thbar], "obs d/dloc, d/dtheta")
+        # the kernel-parameter form (one-launch kernel for the lattices that fit a workgroup, composed otherwise)
+        lp, zbar, lsum, bars, thbar = o.gp_inv_rfft2_obs_lpdf_kernel_vjp(o.OBS_NEG_BINOMIAL_2_LOG, z, np.full((H, W), 0.35), "matern",
+                                                                          1.5, sigma, ls, per, obs, 2.5, nugget=1e-4)
+        close(records[tag + "obsk_lpdf"][0], lp, "obs (kernel) lpdf")
+        close(R("obsk_grad_z", W), zbar, "obs (kernel) d/dz")
+        close(records[tag + "obsk_grad_loc_theta"], [lsum, thbar], "obs (kernel) d/dloc, d/dtheta")
+        covk = mt + 1e-4
+        cbark = o.gp_inv_rfft2_obs_lpdf_vjp(o.OBS_NEG_BINOMIAL_2_LOG, z, np.full((H, W), 0.35), covk, obs, 2.5, True)[5]
+        np.testing.assert_allclose(records[tag + "obsk_grad_par"], np.concatenate([np.ravel(x) for x in bars]), rtol=1e-9,
+                                   atol=1e-10 * float(np.abs(cbark * covk).sum()), err_msg="obs (kernel) d/dparams")
 
 
 @pytest.mark.gpu

@@ -278,3 +278,83 @@ def test_obs_host_entry_point(fft, layout):
     rc = lib.gpt_gp_inv_rfft2_obs_lpdf_host(ctx.handle, _lib.GPT_ROW_MAJOR, 2, P(z), None, 0.0, P(cov), P(obs), 4, 6, -1.0, 0,
                                             4, 6, 0, P(lp), P(gz), None, None, None)
     assert rc == _lib.GPT_ERR_SHAPE and "Precision" in ctx.error()
+
+
+# ---- the same density from kernel parameters (inverse-transform half) --------------------------------
+@pytest.mark.parametrize("shape,window", [((35, 60), (25, 50)), ((64, 64), (64, 64)), ((7, 9), (3, 4)), ((300, 210), (150, 210)),
+                                          ((256, 256), (200, 100)), ((100,), (80,)), ((128,), (128,))], ids=str)
+@pytest.mark.parametrize("family", ["neg_binomial_2_log", "normal", "poisson_log"])
+@pytest.mark.parametrize("kind,nu", [("matern", 1.5), ("matern", 2.5), ("matern", 0.9), ("expquad", 0.0)])
+def test_obs_lpdf_kernel_vjp(fft, shape, window, family, kind, nu):
+    """gpt_gp_inv_rfft2_obs_lpdf_kernel_vjp: the non-centred model density with the spectrum given by (sigma, length_scale,
+    period) + nugget as trees.stan:26-29 builds it, down to d / d(kernel parameters). Lattices that fit a workgroup take the
+    one-launch kernel that never holds the spectrum (half-integer nu and the squared exponential; nu = 0.9 and the 1-D
+    layout compose); against the oracle's composition of the reference functions. Two lattices with different parameters."""
+    dim1 = len(shape) == 1
+    if dim1 and (family != "normal" or kind == "matern" and nu == 2.5):
+        pytest.skip("1-D: one family and fewer kernels (the route is the composed one)")
+    rng = np.random.default_rng(zlib.crc32(repr((shape, family, kind, nu)).encode()))
+    b = 2
+    z = rng.normal(size=(b,) + shape)
+    loc = rng.normal(size=shape)
+    obs, theta = _data(family, rng, window, b)
+    sigma = np.array([1.3, 0.7])
+    eps = 1e-3
+    if dim1:
+        n = shape[0]
+        ls, per = np.array([n / 12.0, n / 20.0]), np.array([float(n), 1.5 * n])
+        res = fft.gp_inv_rfft_obs_lpdf_kernel_vjp(family, z, loc, kind, nu, sigma, ls, per, obs, theta, nugget=eps)
+    else:
+        h, w = shape
+        ls = np.array([[h / 40.0 + 0.5, w / 30.0 + 0.5], [h / 25.0 + 0.5, w / 50.0 + 0.5]])
+        per = np.array([[float(h), float(w)], [1.2 * h, 0.9 * w]])
+        res = fft.gp_inv_rfft2_obs_lpdf_kernel_vjp(family, z, loc, kind, nu, sigma, ls, per, obs, theta, nugget=eps)
+    sb, lb, pb = res["grad_kernel"]
+    for i in range(b):
+        th = None if theta is None else theta[i]
+        f_or = o.gp_inv_rfft_obs_lpdf_kernel_vjp if dim1 else o.gp_inv_rfft2_obs_lpdf_kernel_vjp
+        lp, zbar, lsum, bars, thbar = f_or(FAMILIES[family], z[i], loc, kind, nu, sigma[i], ls[i], per[i], obs, th, nugget=eps)
+        close(res["lp"][i], lp)
+        close(res["grad_z"][i], zbar)
+        close(res["grad_loc_sum"][i], lsum)
+        if theta is not None:
+            close(res["grad_theta"][i], thbar)
+        # the parameter gradients are sums of ~n terms of both signs: tolerance relative to the sum of magnitudes
+        if dim1:
+            cov = (o.gp_periodic_exp_quad_cov_rfft(n, sigma[i], ls[i], per[i]) if kind == "expquad"
+                   else o.gp_periodic_matern_cov_rfft(nu, n, sigma[i], ls[i], per[i])) + eps
+            cbar = o.gp_inv_rfft_obs_lpdf_vjp(FAMILIES[family], z[i], loc, cov, obs, th)[5]
+        else:
+            cov = (o.gp_periodic_exp_quad_cov_rfft2(h, w, sigma[i], ls[i], per[i]) if kind == "expquad"
+                   else o.gp_periodic_matern_cov_rfft2(nu, h, w, sigma[i], ls[i], per[i])) + eps
+            cbar = o.gp_inv_rfft2_obs_lpdf_vjp(FAMILIES[family], z[i], loc, cov, obs, th)[5]
+        scale = float(np.abs(cbar * cov).sum())
+        for got, want, p in zip((sb[i], lb[i], pb[i]), bars, (sigma[i], ls[i], per[i])):
+            np.testing.assert_allclose(np.asarray(got.cpu()), want, rtol=1e-9, atol=1e-9 * scale / float(np.min(np.abs(p))))
+
+
+def test_obs_lpdf_kernel_vjp_agrees_with_the_array_route(fft):
+    """Same lattices through gp_inv_rfft2_obs_lpdf_vjp on a spectrum made by gp_periodic_matern_cov_rfft2 and through the
+    kernel-parameter entry point, 64 chains of the trees shape in one launch each: 1e-12 on everything they share."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    h, w, b = 35, 60, 64
+    z = rng.normal(size=(b, h, w))
+    obs, _ = _data("neg_binomial_2_log", rng, (25, 50), b)
+    theta = rng.gamma(4.0, 0.7, size=b)
+    sigma = rng.gamma(4.0, 0.3, size=b)
+    ls = np.stack([rng.uniform(1.0, 4.0, size=b), rng.uniform(1.0, 4.0, size=b)], axis=-1)
+    per = np.tile(np.array([float(h), float(w)]), (b, 1))
+    cov = fft.gp_periodic_matern_cov_rfft2(1.5, h, w, sigma, ls, per) + 1e-9
+    a = fft.gp_inv_rfft2_obs_lpdf_vjp("neg_binomial_2_log", z, 0.5 * np.ones((h, w)), cov, obs, theta, need_f=False)
+    k = fft.gp_inv_rfft2_obs_lpdf_kernel_vjp("neg_binomial_2_log", z, 0.5 * np.ones((h, w)), "matern", 1.5, sigma, ls, per, obs,
+                                             theta, nugget=1e-9)
+    for key in ("lp", "grad_z", "grad_loc_sum", "grad_theta"):
+        close(k[key], a[key].cpu().numpy(), rtol=1e-12)
+    sbar, lbar, pbar = fft.gp_periodic_matern_cov_rfft2_vjp(1.5, h, w, sigma, ls, per, a["grad_cov"])
+    scale = (a["grad_cov"] * cov).abs().sum(dim=(-2, -1))
+    for got, want in zip(k["grad_kernel"], (sbar, lbar, pbar)):
+        err = (got - want).abs()
+        bound = 1e-11 * (scale if got.dim() == 1 else scale[:, None])
+        assert bool(torch.all(err <= bound)), float((err / bound).max())

@@ -109,7 +109,8 @@ def test_user_header_defines_every_declared_function():
 
     hpp = open(stan.get_user_header()).read()
     decls = _stan_declarations()
-    for fn in HOT_PATH_FUNCTIONS + ["gp_inv_rfft2_obs_lpdf", "gp_inv_rfft_obs_lpdf"]:
+    for fn in HOT_PATH_FUNCTIONS + ["gp_inv_rfft2_obs_lpdf", "gp_inv_rfft_obs_lpdf", "gp_inv_rfft2_obs_matern_lpdf",
+                                    "gp_inv_rfft2_obs_exp_quad_lpdf"]:
         assert fn in decls, f"{fn} is not declared in the .stan files"
         ret, args = decls[fn]
         head, rtype, params = _header_definition(hpp, fn)
@@ -153,10 +154,10 @@ def test_observation_model_extension_is_declared_and_bound():
     inc = stan.get_include()
     text = open(os.path.join(inc, "gptools", "fft_obs.stan")).read()
     hpp = open(stan.get_user_header()).read()
-    for fn in ("gp_inv_rfft2_obs_lpdf", "gp_inv_rfft_obs_lpdf"):
+    for fn in ("gp_inv_rfft2_obs_lpdf", "gp_inv_rfft_obs_lpdf", "gp_inv_rfft2_obs_matern_lpdf", "gp_inv_rfft2_obs_exp_quad_lpdf"):
         assert re.search(rf"^real {fn}\(", text, re.M), fn
         assert re.search(rf"\b{fn}\(", hpp), fn
     bind = open(os.path.join(os.path.dirname(stan.get_user_header()), "gptools_hip_bind.hpp")).read()
-    assert "gpt_gp_inv_rfft2_obs_lpdf_host" in bind
+    assert "gpt_gp_inv_rfft2_obs_lpdf_host" in bind and "gpt_gp_inv_rfft2_obs_lpdf_kernel_host" in bind
     # the reference's own include names stay free of the extension: existing models compile unchanged
     assert "fft_obs" not in open(os.path.join(inc, "gptools", "fft.stan")).read()
