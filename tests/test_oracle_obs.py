@@ -116,3 +116,35 @@ def test_1d_sibling_matches_2d_row():
     np.testing.assert_allclose(f, o.gp_inv_rfft(z, np.zeros(n), cov))
     want = stats.norm.logpdf(y, f[:7], 0.7).sum() + stats.norm.logpdf(z).sum()
     np.testing.assert_allclose(lp, want, rtol=1e-12)
+
+
+@pytest.mark.parametrize("kind,nu", [("matern", 1.5), ("expquad", 0.0)])
+def test_kernel_parameter_form_finite_differences(kind, nu):
+    """gp_inv_rfft2_obs_lpdf_kernel_vjp (the density with the spectrum built from (sigma, length_scale, period) + nugget,
+    trees.stan:26-49): a composition of functions pinned above and in tests/test_oracle_golden.py -- here the chain through
+    all of them against central differences in every kernel parameter, and its 1-D sibling."""
+    rng = np.random.default_rng(8)
+    h, w = 6, 8
+    z = rng.normal(size=(h, w))
+    _, obs, theta = _case(o.OBS_NEG_BINOMIAL_2_LOG, rng)
+    sigma, ls, per = 1.2, np.array([1.1, 1.7]), np.array([6.0, 9.0])
+    args = lambda s, l, p: (o.OBS_NEG_BINOMIAL_2_LOG, z, np.full((h, w), 0.3), kind, nu, s, l, p, obs, theta)  # noqa: E731
+    lp, zbar, lsum, (sb, lb, pb), thbar = o.gp_inv_rfft2_obs_lpdf_kernel_vjp(*args(sigma, ls, per), nugget=1e-3)
+    val = lambda s, l, p: o.gp_inv_rfft2_obs_lpdf_kernel_vjp(*args(s, l, p), nugget=1e-3)[0]  # noqa: E731
+    eps = 1e-6
+    np.testing.assert_allclose(sb, (val(sigma + eps, ls, per) - val(sigma - eps, ls, per)) / (2 * eps), rtol=1e-6)
+    for k in range(2):
+        d = np.zeros(2)
+        d[k] = eps
+        np.testing.assert_allclose(lb[k], (val(sigma, ls + d, per) - val(sigma, ls - d, per)) / (2 * eps), rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(pb[k], (val(sigma, ls, per + d) - val(sigma, ls, per - d)) / (2 * eps), rtol=1e-6, atol=1e-8)
+    # 1-D sibling on one row
+    n = 10
+    z1 = rng.normal(size=n)
+    obs1 = np.array([2.0, 0.0, -1.0, 3.0, 1.0, np.nan, 4.0])
+    a1 = lambda s, l, p: (o.OBS_NEG_BINOMIAL_2_LOG, z1, np.full(n, 0.3), kind, nu, s, l, p, obs1, 1.3)  # noqa: E731
+    lp1, _, _, (sb1, lb1, pb1), _ = o.gp_inv_rfft_obs_lpdf_kernel_vjp(*a1(0.9, 1.4, 10.0), nugget=1e-3)
+    v1 = lambda s, l, p: o.gp_inv_rfft_obs_lpdf_kernel_vjp(*a1(s, l, p), nugget=1e-3)[0]  # noqa: E731
+    np.testing.assert_allclose(sb1, (v1(0.9 + eps, 1.4, 10.0) - v1(0.9 - eps, 1.4, 10.0)) / (2 * eps), rtol=1e-6)
+    np.testing.assert_allclose(lb1, (v1(0.9, 1.4 + eps, 10.0) - v1(0.9, 1.4 - eps, 10.0)) / (2 * eps), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(pb1, (v1(0.9, 1.4, 10.0 + eps) - v1(0.9, 1.4, 10.0 - eps)) / (2 * eps), rtol=1e-6, atol=1e-8)
