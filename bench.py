@@ -285,6 +285,53 @@ def fused_kernel_extra(fft, ctx, y, loc, steps):
     return rec
 
 
+def small_lattice_extra(fft, device):
+    """NOT the headline: BASELINE configs[0] / [2], the shapes of the reference's own docs models, as a sampler farm
+    would run them -- 4096 chains of the 35 x 60 trees lattice per launch (one workgroup per lattice), value +
+    both gradients, every chain its own spectrum; and the trees model density itself (field from z, masked
+    negative-binomial counts on the 25 x 50 corner, white-noise prior, reverse mode) from kernel parameters.
+    Device-resident, outputs preallocated where the shim allows, HIP events around the launches."""
+    h, w, B = 35, 60, 4096
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    y = torch.randn(B, h, w, dtype=torch.float64, device=device, generator=g)
+    loc = torch.zeros(h, w, dtype=torch.float64, device=device)
+    cov = torch.exp(0.3 * torch.randn(B, h, w // 2 + 1, dtype=torch.float64, device=device, generator=g))
+    out = (torch.empty(B, dtype=torch.float64, device=device), torch.empty_like(y), torch.empty_like(cov),
+           torch.empty(B, dtype=torch.float64, device=device))
+
+    def lpdf():
+        fft.gp_rfft2_lpdf_vjp(y, loc, cov, check=False, out=out)
+
+    for _ in range(3):
+        lpdf()
+    sec = event_timed(lpdf, 20)
+    b_alg = 24 * h * w + 16 * h * (w // 2 + 1)
+    rec = {"gp_rfft2_lpdf_vjp": {"what": f"{B} chains of {h} x {w} per launch, one spectrum per chain", "us_per_launch": 1e6 * sec,
+                                 "evals_per_s": B / sec, "achieved_GBps": B * b_alg / sec / 1e9, "frac": B * b_alg / sec / HBM_PEAK,
+                                 "finite": bool(torch.isfinite(out[0]).all())}}
+    obs = torch.poisson(torch.full((25, 50), 2.0, dtype=torch.float64, device=device), generator=g)
+    obs[torch.rand(25, 50, device=device, generator=g) < 0.1] = -1.0
+    theta = torch.full((B,), 1.7, dtype=torch.float64, device=device)
+    sigma = torch.linspace(0.9, 1.3, B, dtype=torch.float64, device=device)
+    ls = torch.tensor([2.5, 3.0], dtype=torch.float64, device=device).expand(B, 2)
+    per = torch.tensor([float(h), float(w)], dtype=torch.float64, device=device).expand(B, 2)
+    half = torch.full((h, w), 0.5, dtype=torch.float64, device=device)
+    res = {}
+
+    def dens():
+        res["r"] = fft.gp_inv_rfft2_obs_lpdf_kernel_vjp("neg_binomial_2_log", y, half, "matern", 1.5, sigma, ls, per, obs, theta,
+                                                        nugget=1e-9, check=False)
+
+    for _ in range(3):
+        dens()
+    sec = event_timed(dens, 20)
+    rec["gp_inv_rfft2_obs_lpdf_kernel_vjp"] = {"what": f"trees model density, {B} chains per launch, Matern-3/2 parameters per chain",
+                                               "us_per_launch": 1e6 * sec, "evals_per_s": B / sec,
+                                               "finite": bool(torch.isfinite(res["r"]["lp"]).all())}
+    return rec
+
+
 def unshared_leg(fft, ctx, size, B, device, steps):
     """The same step with NOTHING shared: every lattice its own loc and its own cov, so that every byte of B_alg is a
     distinct byte that has to come from HBM (in the headline configuration loc and cov are read about once per launch of
@@ -543,7 +590,8 @@ def main():
             result["roofline"]["measured_copy_GBps"] = 10 * 2 * src.numel() * 8 / (1e-3 * c0.elapsed_time(c1)) / 1e9
             del src, dst
         if world == 1 and not args.no_extra:
-            result["extra"] = {"kernel_fused_lpdf": fused_kernel_extra(fft, ctx, y, loc, max(2, min(args.steps, 5)))}
+            result["extra"] = {"kernel_fused_lpdf": fused_kernel_extra(fft, ctx, y, loc, max(2, min(args.steps, 5))),
+                               "docs_shape_35x60": small_lattice_extra(fft, device)}
             # what the roofline fraction means: the same B_alg with nothing shared, and the
             # traffic-only ceiling of the three-pass structure on this box
         if world == 1 and not args.no_extra and not args.no_ceiling:

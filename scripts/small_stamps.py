@@ -18,6 +18,9 @@ PHASES = ["prologue+tw", "load", "rows fwd", "split", "cols fwd", "elementwise",
           "merge", "rows inv", "store"]
 
 
+HOST = "--host" in sys.argv  # one-lattice cases through gpt_gp_rfft2_lpdf_host (row-major) instead of device tensors
+
+
 def main():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     lib.gpt_debug_small_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -31,8 +34,20 @@ def main():
         kshape = (H, W // 2 + 1) if H > 1 else (W // 2 + 1,)
         cov = (torch.rand(kshape, dtype=torch.float64, generator=g) + 0.5).to(dev)
         f = fft.gp_rfft2_lpdf_vjp if H > 1 else fft.gp_rfft_lpdf_vjp
-        for _ in range(5):
-            f(y, loc, cov)
+        if HOST and batch == 1:
+            # the host-pointer call: the kernel reads and writes the caller's arrays in pinned host memory
+            import numpy as np
+            yh, lh, ch = (np.ascontiguousarray(t.cpu().numpy().reshape(H, -1)) for t in (y, loc, cov))
+            lp, gy, gc = np.zeros(1), np.zeros_like(yh), np.zeros_like(ch)
+            P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+            glib = _lib.load()
+            ctx = fft.get_context()
+            for _ in range(5):
+                assert glib.gpt_gp_rfft2_lpdf_host(ctx.handle, _lib.GPT_ROW_MAJOR, P(yh), P(lh), P(ch), H, W, int(H == 1), P(lp), P(gy),
+                                                   P(gc)) == 0
+        else:
+            for _ in range(5):
+                f(y, loc, cov)
         torch.cuda.synchronize()
         buf = (ctypes.c_longlong * 32)()
         rc = lib.gpt_debug_small_stamps(buf, 32)
@@ -41,7 +56,7 @@ def main():
         cyc = st[12] - st[0]
         wall_us = (st[17] - st[16]) / 100.0
         scale = wall_us / cyc if cyc else 0.0
-        rec = {"H": H, "W": W, "batch": batch, "total_us": round(wall_us, 2), "cycles": cyc,
+        rec = {"H": H, "W": W, "batch": batch, "host_pointers": bool(HOST and batch == 1), "total_us": round(wall_us, 2), "cycles": cyc,
                "phases_us": {n: round((st[i + 1] - st[i]) * scale, 2) for i, n in enumerate(PHASES)}}
         rec["last_thread_us"] = {"interior": round((st[21] - st[20]) * scale, 2), "packed col 0": round((st[22] - st[21]) * scale, 2),
                                  "wave sums + barrier": round((st[23] - st[22]) * scale, 2)}
