@@ -187,7 +187,12 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
     const size_t small_budget = (size_t)128 << 20;
     int64_t chunk = (int64_t)(small_budget / per);
     if (chunk < 1) chunk = 1;
-    if (path == 1 && op_has_fwd(op) && chunk < 4) {
+    static const int small_unit_max = [] { // GPT_UNIT_SMALL_MAX: cache-sized units of up to this many lattices give way to large ones
+        const char* e = getenv("GPT_UNIT_SMALL_MAX");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 3;
+    }();
+    if (path == 1 && op_has_fwd(op) && chunk <= small_unit_max) {
         // (lattices so large that a cache-sized unit holds only a few: launch tails matter.) A unit that is neither
         // cache-sized nor many lattices is the worst of both: below 1.5 GiB of workspace the small units stay.
         int64_t big = (int64_t)(unit_budget / per);
