@@ -32,7 +32,7 @@ namespace {
 template <int KMODE>
 __global__ void __launch_bounds__(1024) small_obs_kernel(LatArgs a, SmallObsArgs o, int cap, int sS, SmallStages ss) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* red = reinterpret_cast<double*>(smem); // 5 x 16 doubles (GPT_SMALL_HDR bytes)
+    double* red = reinterpret_cast<double*>(smem); // 8 x 16 doubles (GPT_SMALL_HDR bytes): step 6
     const LdsLine buf0(smem + GPT_SMALL_HDR);
     const LdsLine buf1 = buf0 + cap;
     const int64_t b = blockIdx.x;
