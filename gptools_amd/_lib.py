@@ -59,6 +59,7 @@ _SIGNATURES = {
                                        c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "gpt_gp_inv_rfft2_obs_lpdf_kernel_host": [c_int, c_int, c_int, c_dbl, c_ptr, c_ptr, c_dbl, c_ptr, c_dbl, c_ptr, c_i64,
                                               c_i64, c_dbl, c_int, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "gpt_gp_rfft2_lpdf_kernel_host": [c_int, c_int, c_dbl, c_ptr, c_ptr, c_ptr, c_dbl, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr],
     "gpt_gp_inv_rfft2_vjp_host": [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr],
     "gpt_gp_rfft2_vjp_host": [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr],
     "gpt_rfft2_host": [c_int, c_ptr, c_i64, c_i64, c_ptr],

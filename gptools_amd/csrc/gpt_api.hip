@@ -107,7 +107,6 @@ int run_units(gpt_ctx* c, int op, const LatArgs& a, int path, int64_t chunk, cpl
         if (s.out_lpdf) s.out_lpdf += b0;
         if (s.min_eig) s.min_eig += b0;
         if (s.kpar) s.kpar += b0 * 5;
-        if (s.ksums) s.ksums += b0 * 4;
         if (s.kbar) s.kbar += b0 * 5;
         if (path == 3) {
             HIP_TRY(c, gpt_launch_anyn(c->anyn, op, s, c->stream));
@@ -624,18 +623,21 @@ int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx* c, int matern, double nu, const double
     if (rc) return rc;
     if (!y || !params || !lpdf || !grad_y) return fail(c, GPT_ERR_SHAPE, "y, params, lpdf and grad_y must not be null");
     if (matern && !(nu > 0)) return fail(c, GPT_ERR_SHAPE, "nu must be positive");
+    // (a host entry point's request to let the last launch publish its completion, gpt_ctx::done_*: the composed route
+    // below is several launches and must not hand it to its first one)
+    const bool armed = c->done_armed;
+    c->done_armed = false;
     if (batch == 0) return GPT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     // the fused evaluation knows exp-quad and half-integer Matern smoothness (nu = 0.5, 1.5, ... 5.5)
     const bool nu_ok = !matern || (nu <= 5.5 && nu - std::floor(nu) == 0.5 /* kern_eval */);
     const int path = path_for_shape(H, W);
-    const bool fused = !dim1 && nu_ok &&
-                       (path == 0 || (path == 1 && gpt_pow2_sub_radix(OP_LPDF_KVJP, (int)H, (int)W) != 0));
+    // (the 1-D functions: the one-workgroup kernel only -- its kern_prepare knows fft1.stan:154-176)
+    const bool fused = nu_ok && (path == 0 || (!dim1 && path == 1 && gpt_pow2_sub_radix(OP_LPDF_KVJP, (int)H, (int)W) != 0));
     if (fused) {
-        // the one-workgroup path leaves four sums per lattice for a combine launch; the three-pass path finishes
-        // inside its last pass (finalize_block) and needs no scratch
-        if (path == 0 && (rc = ensure(c, c->kscr, c->kscr_bytes, sizeof(double) * 4 * (size_t)batch)) != GPT_OK) return rc;
-        LatArgs a = base_args(H, W, batch, 0);
+        // both paths finish inside their last kernel (the one-workgroup kernel's last thread, finalize_block of pass C):
+        // no combine launch, no scratch
+        LatArgs a = base_args(H, W, batch, dim1);
         a.x = y; a.x_bs = y_bs;
         a.loc = loc; a.loc_bs = loc_bs;
         a.out = grad_y;
@@ -643,17 +645,12 @@ int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx* c, int matern, double nu, const double
         a.kpar = params;
         a.kmatern = matern ? 1 : 0;
         a.knu = nu;
-        a.kgamma = matern ? gamma_ratio(nu, 0) : 0.0;
+        a.kgamma = matern ? gamma_ratio(nu, dim1) : 0.0;
         a.knugget = nugget;
-        if (path == 0) {
-            a.ksums = c->kscr;
-        } else {
-            a.out_lpdf = lpdf;
-            a.kbar = params_bar;
-        }
-        if ((rc = run_lattice(c, matern ? OP_LPDF_KVJP : OP_LPDF_KVJP_EQ, a)) != GPT_OK) return rc;
-        if (path == 0) HIP_TRY(c, gpt_launch_kvjp_combine(c->kscr, params, batch, lpdf, params_bar, c->stream));
-        return GPT_OK;
+        a.out_lpdf = lpdf;
+        a.kbar = params_bar;
+        c->done_armed = armed && path == 0; // (one launch on the one-workgroup path: it may publish its completion)
+        return run_lattice(c, matern ? OP_LPDF_KVJP : OP_LPDF_KVJP_EQ, a);
     }
     // composed: cov and d/dcov live in scratch, a chunk of lattices at a time (<= ~256 MiB)
     const size_t hwf = (size_t)H * (size_t)(W / 2 + 1);

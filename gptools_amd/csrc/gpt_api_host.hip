@@ -487,6 +487,32 @@ int gpt_gp_rfft2_lpdf_host(gpt_ctx* c, int layout, const double* y, const double
     return s.finish(dm);
 }
 
+// gp_rfft2_lpdf over a spectrum given by its kernel parameters (gpt_gp_rfft2_lpdf_kernel_vjp): y, loc and five numbers
+// go up; the log density, d/dy and the five adjoints come back. loc may be NULL (0). grad_y NULL: the value only.
+int gpt_gp_rfft2_lpdf_kernel_host(gpt_ctx* c, int layout, int matern, double nu, const double* y, const double* loc,
+                                  const double* params, double nugget, int64_t H, int64_t W, int dim1, double* lpdf,
+                                  double* grad_y, double* params_bar) {
+    int rc = check_shape(c, H, W, 1, dim1);
+    if (rc) return rc;
+    if (!y || !params || !lpdf) return fail(c, GPT_ERR_SHAPE, "y, params and lpdf must not be null");
+    const int npar = dim1 ? 3 : 5;
+    Stager s(c, layout, arena_need(H, W, 5));
+    const double* dy = (const double*)s.up(y, H, W, 8);
+    const double* dl = (const double*)s.up(loc, H, W, 8);
+    const double* dpar = (const double*)s.up(params, 1, npar, 8);
+    double* dgy = (double*)s.dev(H, W, 8); // (the fused evaluation always produces d/dy)
+    double* dsc = (double*)s.dev(1, 8, 8); // lpdf, min_eig, params_bar[5]
+    if (s.go()) return s.rc;
+    s.arm(); // (taken up when the call is one launch on the one-workgroup path)
+    if ((rc = gpt_gp_rfft2_lpdf_kernel_vjp(c, matern, nu, dy, 0, dl, 0, dpar, nugget, H, W, 1, dim1, dsc, dgy,
+                                           params_bar ? dsc + 2 : nullptr, dsc + 1)))
+        return rc;
+    s.down(lpdf, dsc, 1, 1, 8);
+    if (grad_y) s.down(grad_y, dgy, H, W, 8);
+    if (params_bar) s.down(params_bar, dsc + 2, 1, npar, 8);
+    return s.finish(dsc + 1);
+}
+
 int gpt_gp_inv_rfft2_vjp_host(gpt_ctx* c, int layout, const double* z, const double* cov, const double* fbar,
                               int64_t H, int64_t W, int dim1, double* zbar, double* covbar) {
     int rc = check_shape(c, H, W, 1, dim1);

@@ -90,7 +90,7 @@ int small_obs_launch(gpt_ctx* c, bool armed, int family, const double* z, int64_
         a.kpar = params;
         a.kmatern = matern ? 1 : 0;
         a.knu = nu;
-        a.kgamma = matern ? std::tgamma(nu + 1.0) / std::tgamma(nu) : 0.0; // fft2.stan:245
+        a.kgamma = matern ? std::tgamma(nu + (dim1 ? 0.5 : 1.0)) / std::tgamma(nu) : 0.0; // fft1.stan:173, fft2.stan:245
         a.knugget = nugget;
     }
     SmallObsArgs o;
@@ -240,9 +240,9 @@ int gpt_gp_inv_rfft2_obs_lpdf_kernel_vjp(gpt_ctx* c, int family, int matern, dou
     c->done_armed = false;
     if (batch == 0) return GPT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    // the in-kernel evaluation knows exp-quad and half-integer Matern smoothness (nu = 0.5, 1.5, ... 5.5), 2-D layout
+    // the in-kernel evaluation knows exp-quad and half-integer Matern smoothness (nu = 0.5, 1.5, ... 5.5)
     const bool nu_ok = !matern || (nu <= 5.5 && nu - std::floor(nu) == 0.5 /* kern_eval */);
-    if (small_obs_enabled() && !dim1 && nu_ok && path_for_shape(H, W) == 0)
+    if (small_obs_enabled() && nu_ok && path_for_shape(H, W) == 0)
         return small_obs_launch(c, armed, family, z, z_bs, loc, loc_bs, nullptr, 0, params, matern, nu, nugget, obs, obs_bs, oh, ow,
                                 theta, prior, H, W, batch, dim1, lp, nullptr, grad_z, nullptr, grad_loc_sum, nullptr, params_bar,
                                 grad_theta, min_eig);

@@ -86,10 +86,8 @@ struct LatArgs {
     const double* kpar;
     int kmatern;
     double knu, kgamma, knugget;
-    double* ksums; // [batch][4]: log density, then the three sums of acc_kern (gpt_launch_kvjp_combine turns them
-                   // into d/d(sigma, length_scale, period)): the one-workgroup path
-    double* kbar;  // [batch][5] d/d(sigma, length_scale, period), or null: the three-pass path writes it (and out_lpdf)
-                   // from the finalize step folded into pass C -- no separate reduction or combine launch
+    double* kbar;  // [batch][5] d/d(sigma, length_scale, period), or null: written (with out_lpdf) by the last thread of the
+                   // one-workgroup kernel / the finalize step folded into pass C -- no separate reduction or combine launch
     // Twiddle table w_{H/4}^m of the sub-line column kernels (gpt_pow2_sub.h); null: whole-column kernels only.
     const cplx* tw_sub;
     // Slab decomposition, layouts that need no copy on either side of the exchange (0 = not used):
@@ -357,6 +355,9 @@ struct KernPre {
     double tn;     // Matern: arg = 1 + tn (s1 + s2)
     double gco;    // f = gco * s / arg (Matern), gco * s (squared exponential)
     int m;         // Matern: nu + 1/2
+    // Matern: ck = camp * (ysel * y + yoff) * arg^-m with y = arg^-1/2 -- (1, 0) for the 2-D density (exponent nu + 1,
+    // fft2.stan:228-247), (0, 1) for the 1-D one (exponent nu + 1/2, fft1.stan:170-176; one-workgroup kernels only)
+    double ysel, yoff;
 };
 __device__ __forceinline__ double gpt_uniform(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
@@ -394,9 +395,11 @@ __device__ __forceinline__ EwPtrs make_ptrs(const LatArgs& a, int64_t b) {
     P.out_c = a.out_c ? a.out_c + b * hwf : nullptr;
     P.edge_cov = nullptr;
     P.edge_dcov = nullptr;
-    P.kpar = a.kpar ? a.kpar + b * 5 : nullptr;
+    P.kpar = a.kpar ? a.kpar + b * (a.dim1 ? 3 : 5) : nullptr;
     P.kp.r1 = P.kp.r2 = P.kp.camp = P.kp.tn = P.kp.gco = 0.0;
     P.kp.m = 0;
+    P.kp.ysel = 1.0;
+    P.kp.yoff = 0.0;
     return P;
 }
 // d lp / d c of one spectrum entry out of the reverse mode of the inverse transform: stored (a null out_cov: the caller
@@ -410,18 +413,23 @@ template <int OP> __device__ __forceinline__ void kern_prepare(const LatArgs& a,
     if (!op_is_kvjp(OP)) return;
     constexpr double PI_ = 3.14159265358979323846;
     const double* par = P.kpar;
-    const double sigma = par[0], l1 = par[1], l2 = par[2], p1 = par[3], p2 = par[4];
-    const double r1 = l1 / p1, r2 = l2 / p2;
-    const double amp = sigma * sigma * (double)a.H * (double)a.W * r1 * r2;
+    // 2-D: (sigma, l1, l2, p1, p2), fft2.stan:206-247. 1-D (a.dim1, H = 1): (sigma, l, p), fft1.stan:154-176 -- the one
+    // axis is the kernel's second (column) axis, r1 = 0 switches the first one off.
+    const double sigma = par[0];
+    const double r1 = a.dim1 ? 0.0 : par[1] / par[3], r2 = a.dim1 ? par[1] / par[2] : par[2] / par[4];
+    const double amp = sigma * sigma * (double)a.H * (double)a.W * (a.dim1 ? r2 : r1 * r2);
     P.kp.r1 = gpt_uniform(r1);
     P.kp.r2 = gpt_uniform(r2);
     if (OP == OP_LPDF_KVJP) {
-        P.kp.camp = gpt_uniform(amp * 4.0 * (PI_ / (2.0 * a.knu)) * a.kgamma);
+        // a.kgamma = tgamma(nu + ndim / 2) / tgamma(nu)
+        P.kp.camp = gpt_uniform(a.dim1 ? amp * sqrt(2.0 * PI_ / a.knu) * a.kgamma : amp * 4.0 * (PI_ / (2.0 * a.knu)) * a.kgamma);
         P.kp.tn = gpt_uniform(2.0 / a.knu * PI_ * PI_);
-        P.kp.gco = gpt_uniform((a.knu + 1.0) * (4.0 * PI_ * PI_ / a.knu));
+        P.kp.gco = gpt_uniform((a.knu + (a.dim1 ? 0.5 : 1.0)) * (4.0 * PI_ * PI_ / a.knu));
         P.kp.m = __builtin_amdgcn_readfirstlane((int)(a.knu + 0.5));
+        P.kp.ysel = a.dim1 ? 0.0 : 1.0;
+        P.kp.yoff = a.dim1 ? 1.0 : 0.0;
     } else {
-        P.kp.camp = gpt_uniform(amp * (2.0 * PI_));
+        P.kp.camp = gpt_uniform(a.dim1 ? amp * sqrt(2.0 * PI_) : amp * (2.0 * PI_));
         P.kp.tn = 0.0;
         P.kp.gco = 4.0 * PI_ * PI_;
         P.kp.m = 0;
@@ -462,7 +470,7 @@ __device__ __forceinline__ KernVal kern_eval(const LatArgs& a, const KernPre& kp
     const double inv = y * y;
     const double i2 = inv * inv, i4 = i2 * i2;
     const double t1 = (kp.m & 1) ? inv : 1.0, t2 = (kp.m & 2) ? i2 : 1.0, t4 = (kp.m & 4) ? i4 : 1.0; // plain selects
-    v.ck = kp.camp * (y * (t1 * t2 * t4));
+    v.ck = kp.camp * (fma(kp.ysel, y, kp.yoff) * (t1 * t2 * t4)); // (2-D: exactly y)
     const double g = kp.gco * inv;
     v.f1 = g * s1;
     v.f2 = g * s2;

@@ -354,30 +354,6 @@ hipError_t gpt_launch_elem(int op, const ElemArgs& e, double* partials, hipStrea
     return hipGetLastError();
 }
 
-__global__ void kvjp_combine_kernel(const double* ksums, const double* params, int64_t batch, double* lpdf,
-                                    double* params_bar) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    const double* k = ksums + 4 * b;
-    const double* p = params + 5 * b;
-    if (lpdf) lpdf[b] = k[0];
-    if (params_bar) {
-        double* o = params_bar + 5 * b;
-        o[0] = 2.0 * k[1] / p[0];     // sigma
-        o[1] = (k[1] - k[2]) / p[1];  // length_scale[0]
-        o[2] = (k[1] - k[3]) / p[2];  // length_scale[1]
-        o[3] = (k[2] - k[1]) / p[3];  // period[0]
-        o[4] = (k[3] - k[1]) / p[4];  // period[1]
-    }
-}
-hipError_t gpt_launch_kvjp_combine(const double* ksums, const double* params, int64_t batch, double* lpdf,
-                                   double* params_bar, hipStream_t st) {
-    if (batch <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kvjp_combine_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, ksums, params, batch,
-                       lpdf, params_bar);
-    return hipGetLastError();
-}
-
 hipError_t gpt_launch_finalize(const double* partials, int nblk, int64_t batch, int K, double add,
                                double* out_sum, double* out_min, hipStream_t st) {
     if (batch <= 0) return hipSuccess;

@@ -104,9 +104,6 @@ hipError_t gpt_launch_elem(int op, const ElemArgs& e, double* partials, hipStrea
 #endif
 hipError_t gpt_launch_finalize(const double* partials, int nblk, int64_t batch, int K, double add,
                                double* out_sum, double* out_min, hipStream_t st);
-// OP_LPDF_KVJP: ksums[batch][4] (finalize of the column pass) + params[batch][5] -> lpdf[batch], params_bar[batch][5]
-hipError_t gpt_launch_kvjp_combine(const double* ksums, const double* params, int64_t batch, double* lpdf,
-                                   double* params_bar, hipStream_t st);
 // Row-major <-> column-major (Stan/Eigen) transposes of a batch of R x C matrices of `esz`-byte elements.
 hipError_t gpt_launch_transpose(const void* in, void* out, int R, int C, int64_t batch, int esz, hipStream_t st);
 // several R[k] x C[k] matrices of esz-byte elements in one launch

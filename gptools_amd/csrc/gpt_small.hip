@@ -201,11 +201,8 @@ __global__ void __launch_bounds__(1024) small_lattice_kernel(LatArgs a, int cap,
         }
         const double lp = s - 0.5 * (double)H * (double)W * 1.8378770664093454836;
         if ((OP == OP_LPDF || op_is_lpdf_vjp(OP) || OP == OP_INV_VJP) && a.out_lpdf) a.out_lpdf[b] = lp;
-        if (op_is_kvjp(OP) && a.ksums) {
-            a.ksums[4 * b] = lp;
-            a.ksums[4 * b + 1] = kk[0];
-            a.ksums[4 * b + 2] = kk[1];
-            a.ksums[4 * b + 3] = kk[2];
+        if (op_is_kvjp(OP) && a.kbar) { // the three sums -> d / d(sigma, length_scale, period), as finalize_block (gpt_common.h)
+            small_kernel_adjoints(a, b, kk[0], kk[1], kk[2], a.kbar);
         }
         if (a.min_eig) a.min_eig[b] = m;
     }

@@ -175,13 +175,7 @@ __global__ void __launch_bounds__(1024) small_obs_kernel(LatArgs a, SmallObsArgs
             if (o.grad_loc_sum) o.grad_loc_sum[b] = t2;
             if (a.min_eig) a.min_eig[b] = t4;
             if (KMODE && o.kbar) { // (as finalize_block, gpt_common.h)
-                const double* par = a.kpar + 5 * b;
-                double* kb = o.kbar + 5 * b;
-                kb[0] = 2.0 * tk[0] / par[0];      // sigma
-                kb[1] = (tk[0] - tk[1]) / par[1];  // length_scale[0]
-                kb[2] = (tk[0] - tk[2]) / par[2];  // length_scale[1]
-                kb[3] = (tk[1] - tk[0]) / par[3];  // period[0]
-                kb[4] = (tk[2] - tk[0]) / par[4];  // period[1]
+                small_kernel_adjoints(a, b, tk[0], tk[1], tk[2], o.kbar);
             }
         }
     }

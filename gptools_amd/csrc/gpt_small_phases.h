@@ -183,3 +183,24 @@ __device__ __forceinline__ void small_packed0(const LatArgs& a, const ZLayout& L
         }
     }
 }
+
+// The three sums of acc_kern over a lattice (k0 = sum cbar ck, k1 / k2 = the same weighted with the first / second axis'
+// logarithmic sensitivity) -> d lp / d(kernel parameters) of lattice b, in the layout of a.kpar: (sigma, l1, l2, p1, p2),
+// or (sigma, l, p) for the 1-D functions (whose one axis is the kernel's second). As finalize_block, gpt_common.h.
+__device__ __forceinline__ void small_kernel_adjoints(const LatArgs& a, int64_t b, double k0, double k1, double k2, double* kbar) {
+    if (a.dim1) {
+        const double* par = a.kpar + 3 * b;
+        double* kb = kbar + 3 * b;
+        kb[0] = 2.0 * k0 / par[0];   // sigma
+        kb[1] = (k0 - k2) / par[1];  // length_scale
+        kb[2] = (k2 - k0) / par[2];  // period
+        return;
+    }
+    const double* par = a.kpar + 5 * b;
+    double* kb = kbar + 5 * b;
+    kb[0] = 2.0 * k0 / par[0];   // sigma
+    kb[1] = (k0 - k1) / par[1];  // length_scale[0]
+    kb[2] = (k0 - k2) / par[2];  // length_scale[1]
+    kb[3] = (k1 - k0) / par[3];  // period[0]
+    kb[4] = (k2 - k0) / par[4];  // period[1]
+}

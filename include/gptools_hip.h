@@ -286,6 +286,12 @@ int gpt_gp_rfft2_log_abs_det_jac_host(gpt_ctx*, int layout, const double* cov, i
 int gpt_gp_rfft2_lpdf_host(gpt_ctx*, int layout, const double* y, const double* loc, const double* cov,
                            int64_t height, int64_t width, int dim1, double* lpdf,
                            double* grad_y /* may be NULL: value only */, double* grad_cov /* may be NULL */);
+/* gpt_gp_rfft2_lpdf_kernel_vjp on host pointers: gp_rfft2_lpdf (fft2.stan:189-192) over gp_periodic_*_cov_rfft2
+ * (fft2.stan:206-247) + nugget in one call; params / params_bar: (sigma, length_scale[0..1], period[0..1]), or (sigma,
+ * length_scale, period) when dim1. loc, grad_y and params_bar may be NULL. */
+int gpt_gp_rfft2_lpdf_kernel_host(gpt_ctx*, int layout, int matern, double nu, const double* y, const double* loc,
+                                  const double* params, double nugget, int64_t height, int64_t width, int dim1,
+                                  double* lpdf, double* grad_y, double* params_bar);
 int gpt_gp_inv_rfft2_vjp_host(gpt_ctx*, int layout, const double* z, const double* cov, const double* fbar,
                               int64_t height, int64_t width, int dim1, double* zbar, double* covbar);
 int gpt_gp_rfft2_vjp_host(gpt_ctx*, int layout, const double* y, const double* loc, const double* cov,

@@ -492,6 +492,122 @@ stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T2__), T3__, GPT_BASE(T4__), T5__>
     return gptools_hip_stan::obs_lpdf<1>(z, family, obs, loc, cov_rfft, theta, prior, 1, "gp_inv_rfft_obs_lpdf");
 }
 
+// ===================================================================================================
+// Extension (gptools/fft_kernel.stan): gp_rfft(2)_lpdf over a spectrum given by its kernel, one call
+// (gpt_gp_rfft2_lpdf_kernel_host): y, loc and the kernel parameters up, the value and their adjoints back.
+namespace gptools_hip_stan {
+// NP = 5: (sigma, length_scale[2], period[2]) for the 2-D functions; NP = 3: (sigma, length_scale, period) for 1-D.
+// `scatter(adj, pbar)` adds adj * pbar[i] to the adjoints of whichever parameters are vars.
+template <int C, bool MATERN, int NP, typename T0, typename T1, typename Scatter>
+inline auto kernel_lpdf(const T0& y, const T1& loc, double nu, const double (&par)[NP], double nugget, int dim1, bool any_par_var,
+                        Scatter scatter, const char* fn) {
+    const Mat<double, C> yv = real_val<C>(y), lv = real_val<C>(loc);
+    const b::Shape s{dim1 ? 1 : yv.rows(), dim1 ? yv.size() : yv.cols(), dim1};
+    b::require_sizes(lv.size() == yv.size(), fn);
+    using ret_t = std::conditional_t<any_var_v<T0, T1> || Scatter::any_var, var, double>;
+    if constexpr (std::is_same_v<ret_t, double>) {
+        (void)any_par_var;
+        return b::gp_kernel_lpdf(MATERN, nu, yv.data(), lv.data(), par, nugget, s, nullptr, nullptr);
+    } else {
+        stan::math::arena_t<Mat<double, C>> gy(yv.rows(), yv.cols());
+        stan::math::arena_t<Eigen::Matrix<double, NP, 1>> pbar;
+        pbar.setZero();
+        const double value = b::gp_kernel_lpdf(MATERN, nu, yv.data(), lv.data(), par, nugget, s, gy.data(),
+                                               any_par_var ? pbar.data() : nullptr);
+        auto ay = stan::math::to_arena(y);
+        auto al = stan::math::to_arena(loc);
+        return ret_t(stan::math::make_callback_var(value, [ay, al, gy, pbar, scatter](auto& vi) mutable {
+            if constexpr (is_var_v<T0>) ay.adj() += vi.adj() * gy;
+            if constexpr (is_var_v<T1>) al.adj() -= vi.adj() * gy;
+            scatter(vi.adj(), pbar);
+        }));
+    }
+}
+// adjoint scatter of (sigma, length_scale[2], period[2]) / (sigma, length_scale, period)
+template <typename TS, typename TL, typename TP> struct KScatter2 {
+    static constexpr bool any_var = any_var_v<TS, TL, TP>;
+    TS sigma;
+    stan::math::arena_t<TL> ls;
+    stan::math::arena_t<TP> pd;
+    template <typename V> void operator()(double adj, const V& pbar) {
+        add_adj(sigma, adj * pbar.coeff(0));
+        if constexpr (is_var_v<TL>) {
+            ls.adj().coeffRef(0) += adj * pbar.coeff(1);
+            ls.adj().coeffRef(1) += adj * pbar.coeff(2);
+        }
+        if constexpr (is_var_v<TP>) {
+            pd.adj().coeffRef(0) += adj * pbar.coeff(3);
+            pd.adj().coeffRef(1) += adj * pbar.coeff(4);
+        }
+    }
+};
+template <typename TS, typename TL, typename TP> struct KScatter1 {
+    static constexpr bool any_var = any_var_v<TS, TL, TP>;
+    TS sigma;
+    TL ls;
+    TP pd;
+    template <typename V> void operator()(double adj, const V& pbar) {
+        add_adj(sigma, adj * pbar.coeff(0));
+        add_adj(ls, adj * pbar.coeff(1));
+        add_adj(pd, adj * pbar.coeff(2));
+    }
+};
+template <bool MATERN, typename T0, typename T1, typename TS, typename TL, typename TP>
+inline auto kernel_lpdf2(const T0& y, const T1& loc, double nu, const TS& sigma, const TL& length_scale, const TP& period,
+                         double nugget, const char* fn) {
+    using stan::math::value_of;
+    b::require_sizes(length_scale.size() == 2 && period.size() == 2, fn);
+    const double par[5] = {value_of(sigma), value_of(length_scale.coeff(0)), value_of(length_scale.coeff(1)),
+                           value_of(period.coeff(0)), value_of(period.coeff(1))};
+    return kernel_lpdf<-1, MATERN, 5>(y, loc, nu, par, nugget, 0, any_var_v<TS, TL, TP>,
+                                      KScatter2<TS, TL, TP>{sigma, stan::math::to_arena(length_scale), stan::math::to_arena(period)}, fn);
+}
+template <bool MATERN, typename T0, typename T1, typename TS, typename TL, typename TP>
+inline auto kernel_lpdf1(const T0& y, const T1& loc, double nu, const TS& sigma, const TL& length_scale, const TP& period,
+                         double nugget, const char* fn) {
+    using stan::math::value_of;
+    const double par[3] = {value_of(sigma), value_of(length_scale), value_of(period)};
+    return kernel_lpdf<1, MATERN, 3>(y, loc, nu, par, nugget, 1, any_var_v<TS, TL, TP>, KScatter1<TS, TL, TP>{sigma, length_scale, period},
+                                     fn);
+}
+}  // namespace gptools_hip_stan
+template <bool propto__, typename T0__, typename T1__, typename T2__, typename T3__, typename T4__, typename T5__, typename T6__,
+          stan::require_all_t<GPT_REQ_MAT(T0__), GPT_REQ_MAT(T1__), stan::is_stan_scalar<T2__>, stan::is_stan_scalar<T3__>,
+                              GPT_REQ_VEC(T4__), GPT_REQ_VEC(T5__), stan::is_stan_scalar<T6__>>* = nullptr>
+stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T1__), T2__, T3__, GPT_BASE(T4__), stan::promote_args_t<GPT_BASE(T5__), T6__>>
+gp_rfft2_matern_lpdf(const T0__& y, const T1__& loc, const T2__& nu, const T3__& sigma, const T4__& length_scale,
+                     const T5__& period, const T6__& nugget, std::ostream* pstream__) {
+    return gptools_hip_stan::kernel_lpdf2<true>(y, loc, stan::math::value_of(nu), sigma, length_scale, period,
+                                                stan::math::value_of(nugget), "gp_rfft2_matern_lpdf");
+}
+template <bool propto__, typename T0__, typename T1__, typename T2__, typename T3__, typename T4__, typename T5__,
+          stan::require_all_t<GPT_REQ_MAT(T0__), GPT_REQ_MAT(T1__), stan::is_stan_scalar<T2__>, GPT_REQ_VEC(T3__), GPT_REQ_VEC(T4__),
+                              stan::is_stan_scalar<T5__>>* = nullptr>
+stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T1__), T2__, GPT_BASE(T3__), GPT_BASE(T4__), T5__>
+gp_rfft2_exp_quad_lpdf(const T0__& y, const T1__& loc, const T2__& sigma, const T3__& length_scale, const T4__& period,
+                       const T5__& nugget, std::ostream* pstream__) {
+    return gptools_hip_stan::kernel_lpdf2<false>(y, loc, 0.0, sigma, length_scale, period, stan::math::value_of(nugget),
+                                                 "gp_rfft2_exp_quad_lpdf");
+}
+template <bool propto__, typename T0__, typename T1__, typename T2__, typename T3__, typename T4__, typename T5__, typename T6__,
+          stan::require_all_t<GPT_REQ_VEC(T0__), GPT_REQ_VEC(T1__), stan::is_stan_scalar<T2__>, stan::is_stan_scalar<T3__>,
+                              stan::is_stan_scalar<T4__>, stan::is_stan_scalar<T5__>, stan::is_stan_scalar<T6__>>* = nullptr>
+stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T1__), T2__, T3__, T4__, stan::promote_args_t<T5__, T6__>>
+gp_rfft_matern_lpdf(const T0__& y, const T1__& loc, const T2__& nu, const T3__& sigma, const T4__& length_scale,
+                    const T5__& period, const T6__& nugget, std::ostream* pstream__) {
+    return gptools_hip_stan::kernel_lpdf1<true>(y, loc, stan::math::value_of(nu), sigma, length_scale, period,
+                                                stan::math::value_of(nugget), "gp_rfft_matern_lpdf");
+}
+template <bool propto__, typename T0__, typename T1__, typename T2__, typename T3__, typename T4__, typename T5__,
+          stan::require_all_t<GPT_REQ_VEC(T0__), GPT_REQ_VEC(T1__), stan::is_stan_scalar<T2__>, stan::is_stan_scalar<T3__>,
+                              stan::is_stan_scalar<T4__>, stan::is_stan_scalar<T5__>>* = nullptr>
+stan::promote_args_t<GPT_BASE(T0__), GPT_BASE(T1__), T2__, T3__, T4__, T5__>
+gp_rfft_exp_quad_lpdf(const T0__& y, const T1__& loc, const T2__& sigma, const T3__& length_scale, const T4__& period,
+                      const T5__& nugget, std::ostream* pstream__) {
+    return gptools_hip_stan::kernel_lpdf1<false>(y, loc, 0.0, sigma, length_scale, period, stan::math::value_of(nugget),
+                                                 "gp_rfft_exp_quad_lpdf");
+}
+
 // ... and with the spectrum given by its kernel (gptools/fft_obs.stan: gp_inv_rfft2_obs_matern_lpdf,
 // gp_inv_rfft2_obs_exp_quad_lpdf): gpt_gp_inv_rfft2_obs_lpdf_kernel_host, five parameters up and their five adjoints back.
 namespace gptools_hip_stan {

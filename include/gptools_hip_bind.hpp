@@ -213,6 +213,16 @@ inline double gp_lpdf(const double* y, const double* loc, const double* cov, Sha
           s.dim1 ? "gp_rfft_lpdf" : "gp_rfft2_lpdf");
     return value;
 }
+// Extension: the same log density over a spectrum given by its kernel (gpt_gp_rfft2_lpdf_kernel_host): par / pbar as for
+// spectrum() below; grad_y and pbar may be null.
+inline double gp_kernel_lpdf(bool matern, double nu, const double* y, const double* loc, const double* par, double nugget,
+                             Shape s, double* grad_y, double* pbar) {
+    double value = 0.0;
+    check(gpt_gp_rfft2_lpdf_kernel_host(ctx(), GPT_COL_MAJOR, matern ? 1 : 0, nu, y, loc, par, nugget, s.H, s.W, s.dim1, &value,
+                                        grad_y, pbar),
+          s.dim1 ? "gp_rfft_kernel_lpdf" : "gp_rfft2_kernel_lpdf");
+    return value;
+}
 // gp_rfft_log_abs_det_jac (fft1.stan:78-82) / gp_rfft2_log_abs_det_jac (fft2.stan:143-173); grad_cov may be null
 inline double gp_ladj(const double* cov, Shape s, double* grad_cov) {
     double value = 0.0;

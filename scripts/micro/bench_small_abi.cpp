@@ -95,9 +95,38 @@ int main() {
                 (layout == GPT_COL_MAJOR ? us_host : us_host_rm) = 1e6 * (now() - t0) / 500;
             }
         }
+        // the same density from kernel parameters (Matern 3/2 + nugget): one host call (gpt_gp_rfft2_lpdf_kernel_host)
+        // against the three the array interface needs (spectrum, density, the spectrum's reverse mode)
+        double us_khost = -1.0, us_3host = -1.0;
+        if (c.batch == 1) {
+            const double par1[3] = {1.1, 0.1 * c.W, (double)c.W}, par2[5] = {1.1, 2.5, 3.0, (double)c.H, (double)c.W};
+            const double* par = dim1 ? par1 : par2;
+            double kb[5];
+            std::vector<double> cv(cov.size());
+            auto khost = [&] {
+                const int rc = gpt_gp_rfft2_lpdf_kernel_host(ctx, GPT_COL_MAJOR, 1, 1.5, y.data(), loc.data(), par, 1e-9, c.H, c.W, dim1, lp.data(),
+                                                             gy.data(), kb);
+                if (rc != GPT_OK) { printf("host call -> %d: %s\n", rc, gpt_last_error(ctx)); exit(1); }
+            };
+            auto three = [&] {
+                GK(gpt_gp_periodic_matern_cov_rfft2_host(ctx, GPT_COL_MAJOR, 1.5, c.H, c.W, par, dim1, cv.data()));
+                for (auto& v : cv) v += 1e-9;
+                GK(gpt_gp_rfft2_lpdf_host(ctx, GPT_COL_MAJOR, y.data(), loc.data(), cv.data(), c.H, c.W, dim1, lp.data(), gy.data(), gc.data()));
+                GK(gpt_gp_periodic_matern_cov_rfft2_vjp_host(ctx, GPT_COL_MAJOR, 1.5, c.H, c.W, par, gc.data(), dim1, kb));
+            };
+            for (int i = 0; i < 20; ++i) khost();
+            t0 = now();
+            for (int i = 0; i < 500; ++i) khost();
+            us_khost = 1e6 * (now() - t0) / 500;
+            for (int i = 0; i < 20; ++i) three();
+            t0 = now();
+            for (int i = 0; i < 500; ++i) three();
+            us_3host = 1e6 * (now() - t0) / 500;
+        }
         printf("{\"case\": \"%s\", \"us_per_call_device_ptr\": %.2f, \"evals_per_s_device_ptr\": %.0f, \"us_per_graph_replay_noalloc\": %.2f, "
-               "\"us_per_call_host_ptr_col_major\": %.2f, \"us_per_call_host_ptr_row_major\": %.2f}\n",
-               c.label, us_dev, c.batch / (1e-6 * us_dev), us_graph, us_host, us_host_rm);
+               "\"us_per_call_host_ptr_col_major\": %.2f, \"us_per_call_host_ptr_row_major\": %.2f, "
+               "\"from_kernel_parameters\": {\"us_per_call_host_ptr_col_major\": %.2f, \"us_three_host_calls_array_interface\": %.2f}}\n",
+               c.label, us_dev, c.batch / (1e-6 * us_dev), us_graph, us_host, us_host_rm, us_khost, us_3host);
         fflush(stdout);
         CK(hipFree(dy)); CK(hipFree(dl)); CK(hipFree(dc)); CK(hipFree(dlp)); CK(hipFree(dgy)); CK(hipFree(dgc)); CK(hipFree(dmn));
     }

@@ -119,6 +119,11 @@ static void run_case(int64_t H, int64_t W, int dim1, uint64_t seed) {
         g::spectrum_vjp(matern, 1.5, s, par, barf.data(), pbar);
         put(tag + k + "_vjp", pbar, np);
     }
+    // gp_rfft(2)_lpdf over the Matern-3/2 spectrum + a nugget, from the kernel parameters
+    v = g::gp_kernel_lpdf(true, 1.5, y.data(), loc.data(), par, 1e-4, s, abar.data(), pbar);
+    put(tag + "klpdf", &v, 1);
+    put(tag + "klpdf_grad_y", abar);
+    put(tag + "klpdf_grad_par", pbar, np);
     // the non-centred model density of docs/trees/trees.stan:31-49 (negative binomial, white-noise prior)
     if (!dim1) {
         const int64_t oh = H - H / 4, ow = W - W / 4;

@@ -194,6 +194,21 @@ def test_bind_functions_vs_oracle(records, case):
         flat = np.concatenate([np.ravel(x) for x in want])
         scale_ = float(np.abs(barf * up(spec)).sum())
         np.testing.assert_allclose(records[tag + name], flat, rtol=1e-9, atol=1e-10 * scale_, err_msg=name)
+    # the log density from kernel parameters (one launch where the lattice fits a workgroup or the column pass evaluates the
+    # kernel; composed otherwise): Matern 3/2 + nugget 1e-4
+    covk = mt + 1e-4
+    if dim1:
+        lpk, gyk, gck = o.gp_rfft_lpdf_vjp(y[0], loc[0], covk)
+        want = o.gp_periodic_matern_cov_rfft_vjp(1.5, W, *par, gck)
+        gyk, covk_, gck_ = gyk[None], covk[None], gck[None]
+    else:
+        lpk, gyk, gck = o.gp_rfft2_lpdf_vjp(y, loc, covk)
+        want = o.gp_periodic_matern_cov_rfft2_vjp(1.5, H, W, sigma, ls, per, gck)
+        covk_, gck_ = covk, gck
+    close(records[tag + "klpdf"][0], lpk, "kernel lpdf")
+    close(R("klpdf_grad_y", W), gyk, "kernel lpdf d/dy")
+    np.testing.assert_allclose(records[tag + "klpdf_grad_par"], np.concatenate([np.ravel(x) for x in want]), rtol=1e-9,
+                               atol=1e-10 * float(np.abs(gck_ * covk_).sum()), err_msg="kernel lpdf d/dparams")
     if not dim1:
         oh, ow = H - H // 4, W - W // 4
         obs = records[tag + "obs"].reshape((oh, ow), order="F")

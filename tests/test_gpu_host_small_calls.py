@@ -80,3 +80,75 @@ def test_many_small_host_calls_in_a_row(fft, shape, layout_name):
             rc = lib.gpt_gp_rfft2_lpdf_host(ctx.handle, layout, P(ya), P(la), P(arr(bad)), h, w, dim1, P(lp), None, None)
             assert rc == _lib.GPT_ERR_NOT_PD
             assert "not positive-definite" in ctx.error()
+
+
+@pytest.mark.parametrize("shape", [(1, 100), (35, 60), (64, 64), (256, 256)], ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("kind,nu", [("matern", 1.5), ("expquad", 0.0)])
+def test_kernel_parameter_host_forms(fft, shape, kind, nu):
+    """gpt_gp_rfft2_lpdf_kernel_host and gpt_gp_inv_rfft2_obs_lpdf_kernel_host (column-major, as the Stan header calls
+    them): (sigma, length_scale, period) + nugget in, the density and every adjoint out in one call; several calls in a
+    row with fresh inputs (one-launch kernels publish their own completion); against the oracle's composition of the
+    reference functions."""
+    from gptools_amd import _lib
+
+    lib = _lib.load()
+    ctx = fft.get_context()
+    h, w = shape
+    dim1 = int(h == 1)
+    rng = np.random.default_rng(77 * h + w)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    F = lambda a: np.asfortranarray(a)  # noqa: E731
+    eps = 1e-3
+    for rep in range(8):
+        y, loc = rng.normal(size=(h, w)), rng.normal(size=(h, w))
+        sigma = float(rng.gamma(4.0, 0.3))
+        if dim1:
+            ls, per = float(rng.uniform(2.0, 6.0)), float(w)
+            par = np.array([sigma, ls, per])
+            cov = (o.gp_periodic_exp_quad_cov_rfft(w, sigma, ls, per) if kind == "expquad"
+                   else o.gp_periodic_matern_cov_rfft(nu, w, sigma, ls, per)) + eps
+            lp_o, gy_o, gc_o = o.gp_rfft_lpdf_vjp(y[0], loc[0], cov)
+            gy_o = gy_o[None]
+            bars = (o.gp_periodic_exp_quad_cov_rfft_vjp(w, sigma, ls, per, gc_o) if kind == "expquad"
+                    else o.gp_periodic_matern_cov_rfft_vjp(nu, w, sigma, ls, per, gc_o))
+        else:
+            ls, per = rng.uniform(1.5, 5.0, size=2), np.array([float(h), float(w)])
+            par = np.concatenate([[sigma], ls, per])
+            cov = (o.gp_periodic_exp_quad_cov_rfft2(h, w, sigma, ls, per) if kind == "expquad"
+                   else o.gp_periodic_matern_cov_rfft2(nu, h, w, sigma, ls, per)) + eps
+            lp_o, gy_o, gc_o = o.gp_rfft2_lpdf_vjp(y, loc, cov)
+            bars = (o.gp_periodic_exp_quad_cov_rfft2_vjp(h, w, sigma, ls, per, gc_o) if kind == "expquad"
+                    else o.gp_periodic_matern_cov_rfft2_vjp(nu, h, w, sigma, ls, per, gc_o))
+        want_bar = np.concatenate([np.ravel(x) for x in bars])
+        scale = float(np.abs(gc_o * cov).sum())
+        lp, gy, pb = np.full(1, np.nan), np.full((h, w), np.nan, order="F"), np.full(par.size, np.nan)
+        ya, la = F(y), F(loc)
+        rc = lib.gpt_gp_rfft2_lpdf_kernel_host(ctx.handle, _lib.GPT_COL_MAJOR, int(kind == "matern"), nu, P(ya), P(la), P(par), eps, h, w,
+                                               dim1, P(lp), P(gy), P(pb))
+        assert rc == 0, ctx.error()
+        close(lp[0], lp_o)
+        close(gy, gy_o)
+        np.testing.assert_allclose(pb, want_bar, rtol=1e-9, atol=1e-9 * scale / float(np.min(np.abs(par))))
+        if dim1:
+            continue
+        # the non-centred model density from the same parameters
+        oh, ow = h - h // 4, w - w // 3
+        obs = rng.poisson(3.0, size=(oh, ow)).astype(float)
+        obs[rng.random((oh, ow)) < 0.1] = -1.0
+        z = rng.normal(size=(h, w))
+        lp2, gl, gt = np.full(1, np.nan), np.full(1, np.nan), np.full(1, np.nan)
+        gz, kb = np.full((h, w), np.nan, order="F"), np.full(5, np.nan)
+        za, oa = F(z), F(obs)
+        rc = lib.gpt_gp_inv_rfft2_obs_lpdf_kernel_host(ctx.handle, _lib.GPT_COL_MAJOR, o.OBS_NEG_BINOMIAL_2_LOG, int(kind == "matern"), nu,
+                                                       P(za), None, 0.4, P(par), eps, P(oa), oh, ow, 2.2, 1, h, w, 0, P(lp2), P(gz), P(gl),
+                                                       P(kb), P(gt))
+        assert rc == 0, ctx.error()
+        lpo, zbar, lsum, kbars, thbar = o.gp_inv_rfft2_obs_lpdf_kernel_vjp(o.OBS_NEG_BINOMIAL_2_LOG, z, np.full((h, w), 0.4), kind, nu, sigma,
+                                                                           ls, per, obs, 2.2, nugget=eps)
+        close(lp2[0], lpo)
+        close(gz, zbar)
+        close(gl[0], lsum)
+        close(gt[0], thbar)
+        cbar = o.gp_inv_rfft2_obs_lpdf_vjp(o.OBS_NEG_BINOMIAL_2_LOG, z, np.full((h, w), 0.4), cov, obs, 2.2)[5]
+        np.testing.assert_allclose(kb, np.concatenate([np.ravel(x) for x in kbars]), rtol=1e-9,
+                                   atol=1e-9 * float(np.abs(cbar * cov).sum()) / float(np.min(np.abs(par))))

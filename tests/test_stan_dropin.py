@@ -81,7 +81,7 @@ def _stan_declarations():
 
     inc = stan.get_include()
     decls = {}
-    for name in ("fft1.stan", "fft2.stan", "util.stan", "fft_obs.stan"):
+    for name in ("fft1.stan", "fft2.stan", "util.stan", "fft_obs.stan", "fft_kernel.stan"):
         text = open(os.path.join(inc, "gptools", name)).read()
         text = re.sub(r"//[^\n]*", "", text)
         for ret, fn, args in re.findall(r"^\s*(\w+)\s+(\w+)\s*\(([^)]*)\)\s*;", text, re.M):
@@ -110,7 +110,8 @@ def test_user_header_defines_every_declared_function():
     hpp = open(stan.get_user_header()).read()
     decls = _stan_declarations()
     for fn in HOT_PATH_FUNCTIONS + ["gp_inv_rfft2_obs_lpdf", "gp_inv_rfft_obs_lpdf", "gp_inv_rfft2_obs_matern_lpdf",
-                                    "gp_inv_rfft2_obs_exp_quad_lpdf"]:
+                                    "gp_inv_rfft2_obs_exp_quad_lpdf", "gp_rfft2_matern_lpdf", "gp_rfft2_exp_quad_lpdf",
+                                    "gp_rfft_matern_lpdf", "gp_rfft_exp_quad_lpdf"]:
         assert fn in decls, f"{fn} is not declared in the .stan files"
         ret, args = decls[fn]
         head, rtype, params = _header_definition(hpp, fn)
@@ -159,5 +160,11 @@ def test_observation_model_extension_is_declared_and_bound():
         assert re.search(rf"\b{fn}\(", hpp), fn
     bind = open(os.path.join(os.path.dirname(stan.get_user_header()), "gptools_hip_bind.hpp")).read()
     assert "gpt_gp_inv_rfft2_obs_lpdf_host" in bind and "gpt_gp_inv_rfft2_obs_lpdf_kernel_host" in bind
+    kt = open(os.path.join(inc, "gptools", "fft_kernel.stan")).read()
+    for fn in ("gp_rfft2_matern_lpdf", "gp_rfft2_exp_quad_lpdf", "gp_rfft_matern_lpdf", "gp_rfft_exp_quad_lpdf"):
+        assert re.search(rf"^real {fn}\(", kt, re.M), fn
+        assert re.search(rf"\b{fn}\(", hpp), fn
+    assert "gpt_gp_rfft2_lpdf_kernel_host" in bind
+    assert "fft_kernel" not in open(os.path.join(inc, "gptools", "fft.stan")).read()
     # the reference's own include names stay free of the extension: existing models compile unchanged
     assert "fft_obs" not in open(os.path.join(inc, "gptools", "fft.stan")).read()
