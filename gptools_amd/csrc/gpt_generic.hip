@@ -1,7 +1,8 @@
 // Generic three-pass path: lattices of ANY shape (mixed radix, arbitrary prime factors) that are too large
 // for one workgroup's LDS (gpt_small.hip) and are not power-of-two sized (gpt_pow2_impl.h). Same structure
-// and the same packed-spectrum workspace as the power-of-two path, with the transforms done by the LDS
-// Stockham routine of gpt_lds_fft.h (ping-pong buffers), so one line of up to 4096 points fits a workgroup:
+// and the same packed-spectrum workspace as the power-of-two path, with the transforms done by the in-place LDS
+// Stockham routine of gpt_lds_fft.h (one buffer; a thread's butterflies wait in registers for the barrier), so one line
+// of up to 4096 points is 64 KB of LDS and two or three workgroups share a CU:
 //   pass A  g_row_fwd  LP row pairs per workgroup: two-for-one real transform, split, pack
 //   pass B  g_col      TC adjacent packed columns per workgroup: column FFT, elementwise stage, inverse FFT
 //   pass C  g_row_inv  LP row pairs per workgroup: merge, inverse transform, store
@@ -18,6 +19,9 @@
 #ifndef GPT_TRACE
 #define GPT_TRACE 0
 #endif
+#ifndef GPT_GEN_XCD_TILES
+#define GPT_GEN_XCD_TILES 1 // (0: tile x of the grid is tile x of the lattice, for A/B builds)
+#endif
 #if GPT_TRACE
 // debug builds only (scripts/trace_gen.py): phase timestamps (100 MHz clock) of thread 0 of column workgroup 1, lattice 0
 __device__ unsigned long long g_gen_trace[16];
@@ -32,8 +36,9 @@ __device__ unsigned long long g_gen_trace[16];
 namespace {
 
 constexpr int G_THREADS = 512;
-constexpr int G_MAX_LINE = 4096;      // longest transform (complex points) held in LDS, twice
-constexpr int G_BUF_ELEMS = 4096;     // elements per ping-pong buffer (64 KB)
+constexpr int G_MAX_LINE = 4096;      // longest transform (complex points) held in LDS
+constexpr int G_BUF_ELEMS = 4096;     // most elements of a workgroup's tile (64 KB)
+constexpr int G_EPT = 8;              // elements a thread holds across the barrier of an in-place stage: G_BUF_ELEMS / G_THREADS
 
 struct GenGeo {
     int NC;      // packed columns
@@ -41,11 +46,11 @@ struct GenGeo {
     int Hp;      // row pairs
     int LP;      // row pairs per workgroup
     int TC;      // columns per workgroup
-    int TCs;     // LDS stride between rows of a column tile (odd)
-    // LDS ping-pong buffers (complex elements each) and workgroup sizes of the row and the column kernels: short lines
-    // take 1024-element buffers (32 KB per workgroup, 256 threads), so that four or five workgroups share a CU and one
-    // loads while another transforms, and a launch of few lattices still fills the chip; only lines of more than 2048
-    // points need the full 4096-element buffers (128 KB: one workgroup per CU). The column kernel sizes its buffer for
+    int TCs;     // LDS stride between rows of a column tile (= TC)
+    // Tile sizes (complex elements; the LDS a launch asks for is the tile itself, not the bucket) and workgroup sizes of
+    // the row and the column kernels: short lines take tiles of up to 1024 elements (<= 16 KB per workgroup, 256 threads),
+    // so that several workgroups share a CU and one loads while another transforms, and a launch of few lattices still
+    // fills the chip; only lines of more than 2048 points need 4096-element tiles (<= 64 KB). The column kernel sizes its tile for
     // eight columns first: tile width (bytes per workspace row) matters more to it than occupancy (301 x 200 x 64
     // lattices: 3-column tiles 204 us, 13-column tiles as before).
     int rbuf, cbuf, rthreads, cthreads;
@@ -67,6 +72,19 @@ GenStages make_stages(const LinePlan& p) {
     return g;
 }
 
+// Column tiles of up to 8192 elements (128 KB, one workgroup of 1024 threads per CU) instead of 4096 (two workgroups of
+// 512): taken for lattices of more than 2048 rows, whose tiles would otherwise be ONE column wide (3000^2: 305 -> 281 us
+// per lattice; 1000^2, 8 columns instead of 4: 22.1 -> 22.9, so not there). GPT_GEN_COL_TILE=4096 / 8192 forces either
+// for every lattice of more than 512 rows (A/B knob, profiles/r03_s_generic_inplace_ab.jsonl).
+constexpr int G_COL_THREADS_MAX = 1024;
+int col_tile_max(int H) {
+    static const int forced = [] {
+        const char* e = getenv("GPT_GEN_COL_TILE");
+        const int n = e ? atoi(e) : 0;
+        return n == 8192 || n == 4096 ? n : 0;
+    }();
+    return forced ? forced : (H > 2048 ? 8192 : G_BUF_ELEMS);
+}
 int buf_for_line(int n) { return n <= 1024 ? 1024 : (n <= 2048 ? 2048 : G_BUF_ELEMS); }
 
 GenGeo make_geo(int H, int W) {
@@ -76,20 +94,27 @@ GenGeo make_geo(int H, int W) {
     g.Hp = (H + 1) / 2;
     g.rbuf = buf_for_line(W);
     g.cbuf = buf_for_line(8 * H); // at least 8 adjacent columns (whole 128-byte lines of the workspace) where LDS allows
+    if (8 * H > G_BUF_ELEMS && col_tile_max(H) > G_BUF_ELEMS) g.cbuf = col_tile_max(H);
     g.rthreads = g.rbuf <= 1024 ? 256 : G_THREADS;
-    g.cthreads = g.cbuf <= 1024 ? 256 : G_THREADS;
     g.LP = g.rbuf / W;
     if (g.LP < 1) g.LP = 1;
     if (g.LP > g.Hp) g.LP = g.Hp;
+    // tile widths that divide or are a multiple of a 128-byte line of the workspace (8 columns): 16, 8, 4, 2, 1 -- a tile
+    // of 10 or 14 columns starts and ends inside lines that its neighbours fetch again
     g.TC = g.cbuf / H;
-    if (g.TC > 16) g.TC = 16;
-    if (g.TC < 1) g.TC = 1;
+    g.TC = g.TC >= 16 ? 16 : g.TC >= 8 ? 8 : g.TC >= 4 ? 4 : g.TC >= 2 ? 2 : 1;
     if (g.TC > g.NC) g.TC = g.NC;
-    g.TCs = g.TC | 1;
-    while ((int64_t)H * g.TCs > g.cbuf && g.TC > 1) { // keep H * TCs within the buffer
-        g.TC -= 1;
-        g.TCs = g.TC | 1;
-    }
+    // threads for G_EPT elements each (a multiple of a wave, at least two): a small tile takes a small workgroup, several
+    // of which then share a CU and a launch of few lattices has no second round of workgroups
+    // (tiles of more than 2048 elements: all 512 threads, whatever the count -- 3000 x 1 with 384 threads: 191 us per
+    // lattice against 170)
+    const int tile = H * g.TC;
+    g.cthreads = tile > 4096 ? G_COL_THREADS_MAX : tile > 2048 ? G_THREADS : ((tile + G_EPT - 1) / G_EPT + 63) / 64 * 64;
+    if (g.cthreads < 128) g.cthreads = 128;
+    // (no padding between the columns of a tile: the stages number their work items ACROSS the columns, so neighbouring
+    // lanes touch neighbouring elements at any tile width, and an odd stride would only cost LDS -- 1000 rows x 4
+    // columns: 80 KB with the stride of 5 that was here, one workgroup per CU; 64 KB, two, without)
+    g.TCs = g.TC;
     g.mW = fastdiv_magic_hd((unsigned)W);
     g.mNC = fastdiv_magic_hd((unsigned)g.NC);
     g.mLP = fastdiv_magic_hd((unsigned)g.LP);
@@ -111,13 +136,13 @@ __device__ __forceinline__ double g_in(const LatArgs& a, int64_t b, int i, int j
 template <int IN_MODE>
 __global__ void __launch_bounds__(G_THREADS) g_row_fwd(LatArgs a, GenGeo g, GenStages st, cplx* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLine cur(smem); // (LDS-typed handles, gpt_lds_fft.h)
-    const LdsLine oth = cur + g.rbuf;
+    const LdsLine cur(smem); // (LDS-typed handle, gpt_lds_fft.h)
     const int64_t b = blockIdx.y;
     const int H = a.H, W = a.W;
     const int r0 = blockIdx.x * g.LP;
     const int nl = min(g.LP, g.Hp - r0);
     const bool weven = (W % 2) == 0;
+#pragma unroll 4
     for (int w = threadIdx.x; w < nl * W; w += blockDim.x) {
         const int l = (int)fastdiv((unsigned)w, (unsigned)W, g.mW), j = w - l * W, r = r0 + l;
         const double re = g_in<IN_MODE>(a, b, 2 * r, j);
@@ -125,7 +150,8 @@ __global__ void __launch_bounds__(G_THREADS) g_row_fwd(LatArgs a, GenGeo g, GenS
         cur[w] = make_double2(re, im);
     }
     __syncthreads();
-    const LdsLine res = fft_lines_lds_tw<false, const cplx*>(cur, oth, a.pw, a.pw.tw, nl, 1, W, st.s, nl == g.LP ? g.mLP : g.mLPtail);
+    fft_lines_lds_ip<false, G_EPT, const cplx*>(cur, a.pw, a.pw.tw, nl, 1, W, st.s, nl == g.LP ? g.mLP : g.mLPtail);
+    const LdsLine res = cur;
     cplx* wsb = ws + (int64_t)b * H * g.wstride;
     for (int w = threadIdx.x; w < 2 * nl * g.NC; w += blockDim.x) {
         const int li = (int)fastdiv((unsigned)w, (unsigned)g.NC, g.mNC), jp = w - li * g.NC;
@@ -151,22 +177,42 @@ __global__ void __launch_bounds__(G_THREADS) g_row_fwd(LatArgs a, GenGeo g, GenS
 }
 
 template <int OP>
-__global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, GenStages st, cplx* __restrict__ ws,
+__global__ void __launch_bounds__(G_COL_THREADS_MAX) g_col(LatArgs a, GenGeo g, GenStages st, cplx* __restrict__ ws,
                                                     double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* red = reinterpret_cast<double*>(smem); // 512 bytes
-    LdsLine cur(smem + 512);
-    LdsLine oth = cur + (g.cbuf + 16);
+    const LdsLine cur(smem + 512);
     const int64_t b = blockIdx.y;
     const int H = a.H;
     const ZLayout L = make_layout(a);
     const EwPtrs P = make_ptrs(a, b);
-    const int j0 = blockIdx.x * g.TC;
+    // Workgroups go round the eight XCDs (each with an L2 of its own) in dispatch order: the tiles of one XCD are made
+    // NEIGHBOURS in memory -- tile x of the grid is tile (x / 8) of the (x % 8)-th eighth of the columns -- so that the
+    // workspace and `cov` lines that narrow tiles (tall lattices: 1 - 4 columns, 16 - 64 bytes of every 128-byte line)
+    // share are fetched by one L2 and not by all eight.
+    const int nfull = (int)gridDim.x >> 3, nrem = (int)gridDim.x & 7, xr = (int)blockIdx.x & 7;
+    const int tile = GPT_GEN_XCD_TILES ? xr * nfull + min(xr, nrem) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int j0 = tile * g.TC;
     const int nc = min(g.TC, g.NC - j0);
     const int sS = g.TCs;
     cplx* wsb = ws + (int64_t)b * H * g.wstride;
     const unsigned mnc = nc == g.TC ? g.mTC : g.mTCtail;
     GMARK(0);
+    // `cov` of the thread's entries (at most G_EPT: the tile has at most G_EPT * blockDim.x elements), asked for before the
+    // workspace loads so that its latency passes behind theirs and the transform's, not in front of the elementwise stage
+    constexpr bool uses_cov = OP != OP_RFFT2 && OP != OP_INV_RFFT2;
+    double cpre[G_EPT];
+    if (uses_cov) {
+#pragma unroll
+        for (int it = 0; it < G_EPT; ++it) {
+            const int w = (int)threadIdx.x + it * (int)blockDim.x;
+            cpre[it] = 1.0;
+            if (w < H * nc) {
+                const int k = (int)fastdiv((unsigned)w, (unsigned)nc, mnc), c = w - k * nc;
+                if (j0 + c != 0) cpre[it] = P.cov[(unsigned)k * (unsigned)L.Wf + (unsigned)(j0 + c)];
+            }
+        }
+    }
     if (op_has_fwd(OP)) {
         // (unrolled: the loads of eight iterations are in flight together; one workgroup per CU has nothing else to hide
         // a memory latency per iteration behind)
@@ -177,21 +223,19 @@ __global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, GenStage
         }
         __syncthreads();
         GMARK(1);
-        const LdsLine res = fft_lines_lds_tw<false, const cplx*>(cur, oth, a.ph, a.ph.tw, nc, sS, 1, st.s, mnc);
-        if (res != cur) {
-            oth = cur;
-            cur = res;
-        }
+        fft_lines_lds_ip<false, G_EPT, const cplx*>(cur, a.ph, a.ph.tw, nc, sS, 1, st.s, mnc);
     }
     GMARK(2);
     EwAcc acc;
     acc_init(acc);
-#pragma unroll 4
-    for (int w = threadIdx.x; w < H * nc; w += blockDim.x) {
+#pragma unroll
+    for (int it = 0; it < G_EPT; ++it) {
+        const int w = (int)threadIdx.x + it * (int)blockDim.x;
+        if (w >= H * nc) break;
         const int k = (int)fastdiv((unsigned)w, (unsigned)nc, mnc), c = w - k * nc;
         const int jp = j0 + c;
         if (jp == 0) continue;
-        const cplx G = ew_interior<OP>(a, L, P, k, jp, cur[k * sS + c], acc);
+        const cplx G = ew_interior_c<OP>(a, L, P, k, jp, cur[k * sS + c], uses_cov ? cpre[it] : 1.0, acc);
         if (op_has_inv(OP)) cur[k * sS + c] = G;
         acc_renorm(acc);
     }
@@ -210,7 +254,8 @@ __global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, GenStage
     __syncthreads();
     GMARK(3);
     if (op_has_inv(OP)) {
-        const LdsLine res = fft_lines_lds_tw<true, const cplx*>(cur, oth, a.ph, a.ph.tw, nc, sS, 1, st.s, mnc);
+        fft_lines_lds_ip<true, G_EPT, const cplx*>(cur, a.ph, a.ph.tw, nc, sS, 1, st.s, mnc);
+        const LdsLine res = cur;
         GMARK(4);
         for (int w = threadIdx.x; w < H * nc; w += blockDim.x) {
             const int k = (int)fastdiv((unsigned)w, (unsigned)nc, mnc), c = w - k * nc;
@@ -231,10 +276,9 @@ __global__ void __launch_bounds__(G_THREADS) g_col(LatArgs a, GenGeo g, GenStage
 }
 
 __global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, GenStages st, double alpha, int add_loc,
-                                                       const cplx* __restrict__ ws) {
+                                                       const cplx* __restrict__ ws, FinArgs fin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLine cur(smem);
-    const LdsLine oth = cur + g.rbuf;
     const int64_t b = blockIdx.y;
     const int H = a.H, W = a.W;
     const int r0 = blockIdx.x * g.LP;
@@ -260,7 +304,8 @@ __global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, GenS
         cur[w] = make_double2(A.x - B.y, A.y + B.x);
     }
     __syncthreads();
-    const LdsLine res = fft_lines_lds_tw<true, const cplx*>(cur, oth, a.pw, a.pw.tw, nl, 1, W, st.s, nl == g.LP ? g.mLP : g.mLPtail);
+    fft_lines_lds_ip<true, G_EPT, const cplx*>(cur, a.pw, a.pw.tw, nl, 1, W, st.s, nl == g.LP ? g.mLP : g.mLPtail);
+    const LdsLine res = cur;
     double* ob = a.out + b * (int64_t)H * W;
     for (int w = threadIdx.x; w < nl * W; w += blockDim.x) {
         const int l = (int)fastdiv((unsigned)w, (unsigned)W, g.mW), j = w - l * W, r = r0 + l;
@@ -272,6 +317,11 @@ __global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, GenS
             if (add_loc && a.loc) o += a.loc[b * a.loc_bs + (int64_t)i * W + j];
             ob[(int64_t)i * W + j] = o;
         }
+    }
+    if (fin.partials && blockIdx.x == 0) {
+        // the column pass left per-workgroup partials: the first workgroup of every lattice adds them up (saves a launch)
+        __syncthreads();
+        finalize_block(fin, b, reinterpret_cast<double*>(smem));
     }
 }
 
@@ -290,10 +340,10 @@ hipError_t raise_lds_cap(const void* kernel, std::atomic<uint64_t>& done, int by
 
 template <int OP>
 hipError_t launch_col(const LatArgs& a, const GenGeo& g, cplx* ws, double* partials, int nblk, hipStream_t st) {
-    const size_t lds = 512 + 2 * (size_t)(g.cbuf + 16) * sizeof(cplx);
+    const size_t lds = 512 + ((size_t)a.H * g.TCs + 16) * sizeof(cplx);
     static std::atomic<uint64_t> done{0};
     hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&g_col<OP>), done,
-                                 (int)(512 + 2 * (size_t)(G_BUF_ELEMS + 16) * sizeof(cplx)));
+                                 (int)(512 + (size_t)(2 * G_BUF_ELEMS + 16) * sizeof(cplx)));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(g_col<OP>, dim3(nblk, (unsigned)a.batch), dim3(g.cthreads), lds, st, a, g, make_stages(a.ph), ws,
                        partials);
@@ -301,10 +351,10 @@ hipError_t launch_col(const LatArgs& a, const GenGeo& g, cplx* ws, double* parti
 }
 
 template <int IN_MODE> hipError_t launch_row_fwd(const LatArgs& a, const GenGeo& g, cplx* ws, hipStream_t st) {
-    const size_t lds = 2 * (size_t)g.rbuf * sizeof(cplx);
+    const size_t lds = (size_t)g.LP * a.W * sizeof(cplx);
     static std::atomic<uint64_t> done{0};
     hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&g_row_fwd<IN_MODE>), done,
-                                 (int)(2 * (size_t)G_BUF_ELEMS * sizeof(cplx)));
+                                 (int)((size_t)G_BUF_ELEMS * sizeof(cplx)));
     if (e != hipSuccess) return e;
     const int nb = (g.Hp + g.LP - 1) / g.LP;
     hipLaunchKernelGGL(g_row_fwd<IN_MODE>, dim3(nb, (unsigned)a.batch), dim3(g.rthreads), lds, st, a, g, make_stages(a.pw), ws);
@@ -350,11 +400,16 @@ hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partia
     default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
+    FinArgs fin = {nullptr, 0, 0.0, nullptr, nullptr, nullptr, nullptr};
     if (op != OP_RFFT2 && op != OP_INV_RFFT2) {
         const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op) || op == OP_INV_VJP); // (OP_INV_VJP: the z prior)
-        e = gpt_launch_finalize(partials, nblk, a.batch, 1, -0.5 * n * 1.8378770664093454836,
-                                lp ? a.out_lpdf : nullptr, a.min_eig, st);
-        if (e != hipSuccess) return e;
+        const double add = -0.5 * n * 1.8378770664093454836;
+        if (op_has_inv(op)) { // pass C adds the partials up
+            fin = FinArgs{partials, nblk, add, lp ? a.out_lpdf : nullptr, a.min_eig, nullptr, nullptr};
+        } else {
+            e = gpt_launch_finalize(partials, nblk, a.batch, 1, add, lp ? a.out_lpdf : nullptr, a.min_eig, st);
+            if (e != hipSuccess) return e;
+        }
     }
     if (op_has_inv(op)) {
         double alpha = 1.0;
@@ -362,13 +417,13 @@ hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partia
         if (op == OP_INV_RFFT2) alpha = 1.0 / n;
         else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
         else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
-        const size_t lds = 2 * (size_t)g.rbuf * sizeof(cplx);
+        const size_t lds = (size_t)g.LP * a.W * sizeof(cplx);
         static std::atomic<uint64_t> done{0};
-        e = raise_lds_cap(reinterpret_cast<const void*>(&g_row_inv), done, (int)(2 * (size_t)G_BUF_ELEMS * sizeof(cplx)));
+        e = raise_lds_cap(reinterpret_cast<const void*>(&g_row_inv), done, (int)((size_t)G_BUF_ELEMS * sizeof(cplx)));
         if (e != hipSuccess) return e;
         const int nb = (g.Hp + g.LP - 1) / g.LP;
         hipLaunchKernelGGL(g_row_inv, dim3(nb, (unsigned)a.batch), dim3(g.rthreads), lds, st, a, g, make_stages(a.pw), alpha,
-                           add_loc, ws);
+                           add_loc, ws, fin);
         e = hipGetLastError();
     }
     return e;

@@ -98,6 +98,82 @@ __host__ __device__ __forceinline__ StageK stage_consts(int N, int R, int Ns) {
     k.mNs = fastdiv_magic_hd((unsigned)Ns);
     return k;
 }
+// The R-point butterfly of one work item: inputs x[0..R) (already multiplied by their twiddles), outputs to out[p * os].
+// OUT: anything indexable that yields an assignable reference (an LDS line, or a register array with os = 1).
+template <int R, bool INVERSE, typename OUT> __device__ __forceinline__ void bfly_store(cplx (&x)[R], const OUT out, const int os) {
+    if constexpr (R == 2) {
+        out[0] = cadd(x[0], x[1]);
+        out[os] = csub(x[0], x[1]);
+    } else if constexpr (R == 4) {
+        const cplx a = cadd(x[0], x[2]), b = csub(x[0], x[2]), c = cadd(x[1], x[3]), d0 = csub(x[1], x[3]);
+        const cplx d = INVERSE ? make_double2(-d0.y, d0.x) : make_double2(d0.y, -d0.x); // -+ i (x1 - x3)
+        out[0] = cadd(a, c);
+        out[os] = cadd(b, d);
+        out[2 * os] = csub(a, c);
+        out[3 * os] = csub(b, d);
+    } else if constexpr (R == 3) {
+        constexpr double s3 = 0.86602540378443864676; // sin(2 pi / 3)
+        const cplx t = cadd(x[1], x[2]), u = csub(x[1], x[2]);
+        const cplx m1 = make_double2(fma(-0.5, t.x, x[0].x), fma(-0.5, t.y, x[0].y));
+        // -+ i s3 u
+        const cplx m2 = INVERSE ? make_double2(-s3 * u.y, s3 * u.x) : make_double2(s3 * u.y, -s3 * u.x);
+        out[0] = cadd(x[0], t);
+        out[os] = cadd(m1, m2);
+        out[2 * os] = csub(m1, m2);
+    } else if constexpr (R == 5) {
+        constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410; // cos(2 pi / 5), cos(4 pi / 5)
+        constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917; // sin(2 pi / 5), sin(4 pi / 5)
+        const cplx t1 = cadd(x[1], x[4]), t2 = cadd(x[2], x[3]), t3 = csub(x[1], x[4]), t4 = csub(x[2], x[3]);
+        const cplx a1 = make_double2(fma(c1, t1.x, fma(c2, t2.x, x[0].x)), fma(c1, t1.y, fma(c2, t2.y, x[0].y)));
+        const cplx a2 = make_double2(fma(c2, t1.x, fma(c1, t2.x, x[0].x)), fma(c2, t1.y, fma(c1, t2.y, x[0].y)));
+        const cplx b1 = make_double2(fma(s1, t3.x, s2 * t4.x), fma(s1, t3.y, s2 * t4.y));
+        const cplx b2 = make_double2(fma(s2, t3.x, -s1 * t4.x), fma(s2, t3.y, -s1 * t4.y));
+        // forward: X1 = a1 - i b1, X4 = a1 + i b1, X2 = a2 - i b2, X3 = a2 + i b2 (inverse: the signs swap)
+        const cplx ib1 = INVERSE ? make_double2(-b1.y, b1.x) : make_double2(b1.y, -b1.x);
+        const cplx ib2 = INVERSE ? make_double2(-b2.y, b2.x) : make_double2(b2.y, -b2.x);
+        out[0] = make_double2(x[0].x + t1.x + t2.x, x[0].y + t1.y + t2.y);
+        out[os] = cadd(a1, ib1);
+        out[2 * os] = cadd(a2, ib2);
+        out[3 * os] = csub(a2, ib2);
+        out[4 * os] = csub(a1, ib1);
+    } else if constexpr (R == 8 || R == 16) { // register butterflies of the power-of-two kernels: one LDS pass for 3 / 4 bits
+        pow2::Bfly<R, INVERSE>::run(x);
+#pragma unroll
+        for (int p = 0; p < R; ++p) out[p * os] = x[p];
+    } else {
+        // odd prime radix (7, 11, 13), inputs paired about the middle: with s_q = x_q + x_{R-q}, d_q = x_q - x_{R-q},
+        //   X_p = a_p -+ i b_p,  X_{R-p} = a_p +- i b_p,  a_p = x_0 + sum_q s_q cos(2 pi p q / R),  b_p = sum_q d_q sin(...)
+        // -- (R - 1)^2 real multiply-adds instead of the 4 (R - 1)^2 of the plain R-point sum
+        constexpr int h = (R - 1) / 2;
+        cplx sq[h], dq[h];
+#pragma unroll
+        for (int q = 1; q <= h; ++q) {
+            sq[q - 1] = cadd(x[q], x[R - q]);
+            dq[q - 1] = csub(x[q], x[R - q]);
+        }
+        cplx o0 = x[0];
+#pragma unroll
+        for (int q = 0; q < h; ++q) o0 = cadd(o0, sq[q]);
+        out[0] = o0;
+#pragma unroll
+        for (int p = 1; p <= h; ++p) {
+            cplx av = x[0], bv = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int q = 1; q <= h; ++q) {
+                constexpr_root<R> rt(p * q);
+                av.x = fma(sq[q - 1].x, rt.c, av.x);
+                av.y = fma(sq[q - 1].y, rt.c, av.y);
+                bv.x = fma(dq[q - 1].x, rt.s, bv.x);
+                bv.y = fma(dq[q - 1].y, rt.s, bv.y);
+            }
+            // forward: X_p = a - i b, X_{R-p} = a + i b (inverse: the other way round)
+            const cplx lo = make_double2(av.x + bv.y, av.y - bv.x), hi2 = make_double2(av.x - bv.y, av.y + bv.x);
+            out[p * os] = INVERSE ? hi2 : lo;
+            out[(R - p) * os] = INVERSE ? lo : hi2;
+        }
+    }
+}
+
 template <int R, bool INVERSE, typename TWP>
 __device__ __forceinline__ void stage_lds(const LdsLine src, const LdsLine dst, TWP tw, const StageK& sk, int nlines,
                                           unsigned mL, int es, int ls) {
@@ -138,77 +214,7 @@ __device__ __forceinline__ void stage_lds(const LdsLine src, const LdsLine dst, 
         }
         const LdsLine out = dst + (line * ls + (hi * Ns * R + k) * es);
         const int os = Ns * es;
-        if constexpr (R == 2) {
-            out[0] = cadd(x[0], x[1]);
-            out[os] = csub(x[0], x[1]);
-        } else if constexpr (R == 4) {
-            const cplx a = cadd(x[0], x[2]), b = csub(x[0], x[2]), c = cadd(x[1], x[3]), d0 = csub(x[1], x[3]);
-            const cplx d = INVERSE ? make_double2(-d0.y, d0.x) : make_double2(d0.y, -d0.x); // -+ i (x1 - x3)
-            out[0] = cadd(a, c);
-            out[os] = cadd(b, d);
-            out[2 * os] = csub(a, c);
-            out[3 * os] = csub(b, d);
-        } else if constexpr (R == 3) {
-            constexpr double s3 = 0.86602540378443864676; // sin(2 pi / 3)
-            const cplx t = cadd(x[1], x[2]), u = csub(x[1], x[2]);
-            const cplx m1 = make_double2(fma(-0.5, t.x, x[0].x), fma(-0.5, t.y, x[0].y));
-            // -+ i s3 u
-            const cplx m2 = INVERSE ? make_double2(-s3 * u.y, s3 * u.x) : make_double2(s3 * u.y, -s3 * u.x);
-            out[0] = cadd(x[0], t);
-            out[os] = cadd(m1, m2);
-            out[2 * os] = csub(m1, m2);
-        } else if constexpr (R == 5) {
-            constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410; // cos(2 pi / 5), cos(4 pi / 5)
-            constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917; // sin(2 pi / 5), sin(4 pi / 5)
-            const cplx t1 = cadd(x[1], x[4]), t2 = cadd(x[2], x[3]), t3 = csub(x[1], x[4]), t4 = csub(x[2], x[3]);
-            const cplx a1 = make_double2(fma(c1, t1.x, fma(c2, t2.x, x[0].x)), fma(c1, t1.y, fma(c2, t2.y, x[0].y)));
-            const cplx a2 = make_double2(fma(c2, t1.x, fma(c1, t2.x, x[0].x)), fma(c2, t1.y, fma(c1, t2.y, x[0].y)));
-            const cplx b1 = make_double2(fma(s1, t3.x, s2 * t4.x), fma(s1, t3.y, s2 * t4.y));
-            const cplx b2 = make_double2(fma(s2, t3.x, -s1 * t4.x), fma(s2, t3.y, -s1 * t4.y));
-            // forward: X1 = a1 - i b1, X4 = a1 + i b1, X2 = a2 - i b2, X3 = a2 + i b2 (inverse: the signs swap)
-            const cplx ib1 = INVERSE ? make_double2(-b1.y, b1.x) : make_double2(b1.y, -b1.x);
-            const cplx ib2 = INVERSE ? make_double2(-b2.y, b2.x) : make_double2(b2.y, -b2.x);
-            out[0] = make_double2(x[0].x + t1.x + t2.x, x[0].y + t1.y + t2.y);
-            out[os] = cadd(a1, ib1);
-            out[2 * os] = cadd(a2, ib2);
-            out[3 * os] = csub(a2, ib2);
-            out[4 * os] = csub(a1, ib1);
-        } else if constexpr (R == 8 || R == 16) { // register butterflies of the power-of-two kernels: one LDS pass for 3 / 4 bits
-            pow2::Bfly<R, INVERSE>::run(x);
-#pragma unroll
-            for (int p = 0; p < R; ++p) out[p * os] = x[p];
-        } else {
-            // odd prime radix (7, 11, 13), inputs paired about the middle: with s_q = x_q + x_{R-q}, d_q = x_q - x_{R-q},
-            //   X_p = a_p -+ i b_p,  X_{R-p} = a_p +- i b_p,  a_p = x_0 + sum_q s_q cos(2 pi p q / R),  b_p = sum_q d_q sin(...)
-            // -- (R - 1)^2 real multiply-adds instead of the 4 (R - 1)^2 of the plain R-point sum
-            constexpr int h = (R - 1) / 2;
-            cplx sq[h], dq[h];
-#pragma unroll
-            for (int q = 1; q <= h; ++q) {
-                sq[q - 1] = cadd(x[q], x[R - q]);
-                dq[q - 1] = csub(x[q], x[R - q]);
-            }
-            cplx o0 = x[0];
-#pragma unroll
-            for (int q = 0; q < h; ++q) o0 = cadd(o0, sq[q]);
-            out[0] = o0;
-#pragma unroll
-            for (int p = 1; p <= h; ++p) {
-                cplx av = x[0], bv = make_double2(0.0, 0.0);
-#pragma unroll
-                for (int q = 1; q <= h; ++q) {
-                    constexpr_root<R> rt(p * q);
-                    av.x = fma(sq[q - 1].x, rt.c, av.x);
-                    av.y = fma(sq[q - 1].y, rt.c, av.y);
-                    bv.x = fma(dq[q - 1].x, rt.s, bv.x);
-                    bv.y = fma(dq[q - 1].y, rt.s, bv.y);
-                }
-                // forward: X_p = a - i b, X_{R-p} = a + i b (inverse: the other way round)
-                const cplx lo = make_double2(av.x + bv.y, av.y - bv.x), hi2 = make_double2(av.x - bv.y, av.y + bv.x);
-                out[p * os] = INVERSE ? hi2 : lo;
-                out[(R - p) * os] = INVERSE ? lo : hi2;
-            }
-        }
+        bfly_store<R, INVERSE>(x, out, os);
     }
 }
 
@@ -296,6 +302,140 @@ __device__ GPT_LDS_FFT_INLINE LdsLine fft_lines_lds_tw(LdsLine src, LdsLine dst,
         Ns *= R;
     }
     return src;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same stages IN PLACE: one LDS buffer instead of two. Every thread reads the inputs of all its butterflies into
+// registers, the workgroup meets at a barrier, then the butterflies are done and written to their Stockham positions of
+// the SAME buffer (a second barrier ends the stage). The registers are the second buffer: EPT = elements a thread may
+// hold (the caller keeps nlines * N <= EPT * blockDim.x), so a stage of radix R runs ceil(EPT / R) butterflies per
+// thread. Twice the barriers of the ping-pong form and half its LDS: for the three-pass kernels of gpt_generic.hip, whose
+// tiles are memory latency and want two or three workgroups on a CU (the one-workgroup kernels keep the ping-pong form).
+template <int R, bool INVERSE, int EPT, typename TWP>
+__device__ __forceinline__ void stage_lds_ip(const LdsLine buf, TWP tw, const StageK& sk, int nlines, unsigned mL, int es,
+                                             int ls) {
+    constexpr int IT = (EPT + R - 1) / R;
+    const int Ns = sk.Ns, M = sk.M, tstep = sk.tstep, total = nlines * M;
+    const unsigned mM = sk.mM, mNs = sk.mNs;
+    const bool across = (ls == 1 && es > 1); // (as in stage_lds)
+    cplx x[IT][R];
+    int oo[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int w = (int)threadIdx.x + it * (int)blockDim.x;
+        oo[it] = 0;
+        if (w < total) {
+            int line, j;
+            if (across) {
+                j = (int)fastdiv((unsigned)w, (unsigned)nlines, mL);
+                line = w - j * nlines;
+            } else {
+                line = (int)fastdiv((unsigned)w, (unsigned)M, mM);
+                j = w - line * M;
+            }
+            const int hi = (int)fastdiv((unsigned)j, (unsigned)Ns, mNs), k = j - hi * Ns;
+            const LdsLine in = buf + (line * ls + j * es);
+#pragma unroll
+            for (int q = 0; q < R; ++q) x[it][q] = in[q * M * es];
+            if (Ns > 1) {
+                const int e = k * tstep;
+#pragma unroll
+                for (int q = 1; q < R; ++q) {
+                    // (twiddles from a table in LDS instead: bounded by a build that computes a stand-in and loads nothing --
+                    // 13 % of a 1000 x 4 column tile, 14 % of 3000 x 1, nothing at 192 x 8; not worth the LDS)
+                    cplx t = tw[q * e];
+                    if (INVERSE) t.y = -t.y;
+                    x[it][q] = cmul(x[it][q], t);
+                }
+            }
+            oo[it] = line * ls + (hi * Ns * R + k) * es;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int w = (int)threadIdx.x + it * (int)blockDim.x;
+        if (w < total) bfly_store<R, INVERSE>(x[it], buf + oo[it], Ns * es);
+    }
+    __syncthreads();
+}
+
+// any other prime radix, in place: one work item = one OUTPUT element, a thread's outputs wait in registers for the barrier
+template <bool INVERSE, int EPT, typename TWP>
+__device__ __forceinline__ void stage_lds_ip_prime(const LdsLine buf, TWP ptw, const StageK& sk, int N, int nlines, unsigned mL,
+                                                   int es, int ls) {
+    const int R = sk.R, Ns = sk.Ns, M = sk.M, tstep = sk.tstep, total = nlines * N;
+    const unsigned mN = fastdiv_magic((unsigned)N), mNs = sk.mNs, mR = fastdiv_magic((unsigned)R);
+    const bool across = (ls == 1 && es > 1);
+    cplx y[EPT];
+    int oo[EPT];
+#pragma unroll
+    for (int it = 0; it < EPT; ++it) {
+        const int w = (int)threadIdx.x + it * (int)blockDim.x;
+        oo[it] = 0;
+        y[it] = make_double2(0.0, 0.0);
+        if (w < total) {
+            int line, o;
+            if (across) {
+                o = (int)fastdiv((unsigned)w, (unsigned)nlines, mL);
+                line = w - o * nlines;
+            } else {
+                line = (int)fastdiv((unsigned)w, (unsigned)N, mN);
+                o = w - line * N;
+            }
+            const int t = (int)fastdiv((unsigned)o, (unsigned)Ns, mNs);
+            const int k = o - t * Ns;
+            const int th = (int)fastdiv((unsigned)t, (unsigned)R, mR);
+            const int pp = t - th * R;
+            const int j = th * Ns + k;
+            const int base = (int)(((int64_t)k * tstep + (int64_t)pp * M) % N);
+            const LdsLine in = buf + (line * ls + j * es);
+            double ar = 0.0, ai = 0.0;
+            int e = 0;
+            for (int q = 0; q < R; ++q) {
+                const cplx v = in[q * M * es];
+                cplx tw = ptw[e];
+                if (INVERSE) tw.y = -tw.y;
+                ar = fma(v.x, tw.x, ar);
+                ar = fma(-v.y, tw.y, ar);
+                ai = fma(v.x, tw.y, ai);
+                ai = fma(v.y, tw.x, ai);
+                e += base;
+                if (e >= N) e -= N;
+            }
+            y[it] = make_double2(ar, ai);
+            oo[it] = line * ls + o * es;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < EPT; ++it) {
+        const int w = (int)threadIdx.x + it * (int)blockDim.x;
+        if (w < total) buf[oo[it]] = y[it];
+    }
+    __syncthreads();
+}
+
+// all the stages of plan `p` over `nlines` lines of `buf`, in place (stage constants and the magic of nlines from the host);
+// the caller's data must be visible (a barrier) before the call, the result is visible to the whole workgroup after it
+template <bool INVERSE, int EPT, typename TWP>
+__device__ __forceinline__ void fft_lines_lds_ip(const LdsLine buf, const LinePlan& p, TWP ptw, int nlines, int es, int ls,
+                                                 const StageK* stages, unsigned mL) {
+    for (int s = 0; s < p.ns; ++s) {
+        const StageK sk = stages[s];
+        switch (sk.R) {
+        case 2: stage_lds_ip<2, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+        case 3: stage_lds_ip<3, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+        case 4: stage_lds_ip<4, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+        case 5: stage_lds_ip<5, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+        case 7: stage_lds_ip<7, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+        case 8: stage_lds_ip<8, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+        case 11: stage_lds_ip<11, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+        case 13: stage_lds_ip<13, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+        case 16: stage_lds_ip<16, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+        default: stage_lds_ip_prime<INVERSE, EPT, TWP>(buf, ptw, sk, p.n, nlines, mL, es, ls); break;
+        }
+    }
 }
 
 // twiddles where the plan has them (global memory)

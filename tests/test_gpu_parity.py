@@ -320,7 +320,10 @@ def test_host_entry_points_row_major_small_calls(fft, shape):
 BIG_SHAPES = [(256, 256), (256, 512), (512, 256), (1024, 256), (2048, 512), (512, 2048), (8192, 256), (256, 8192),
               (256, 16384),  # every line length of the power-of-two kernels
               (1024, 1024), (2048, 1024), (1024, 2048), (8192, 1024), (1024, 4096), (4096, 2048),  # sub-line kernels
-              (110, 110), (90, 125), (128, 128), (301, 200), (5, 3000), (2500, 6)]  # generic three-pass path
+              (110, 110), (90, 125), (128, 128), (301, 200), (5, 3000), (2500, 6),  # generic three-pass path
+              # ... its column-tile geometries (gpt_generic.hip make_geo): 4 columns x 512 threads, 2 columns x 1024 threads in
+              # nine tiles (tile numbering by XCD with a ragged last eighth), 4 of 6 possible columns, 8 columns x 256 threads
+              (1000, 40), (3000, 36), (600, 50), (192, 200), (160, 1000)]
 
 
 @pytest.mark.parametrize("shape", BIG_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
