@@ -24,7 +24,8 @@
 namespace {
 
 constexpr int A_THREADS = 512;
-constexpr int A_BUF = 4096;                          // complex elements per LDS ping-pong buffer
+constexpr int A_BUF = 4096;                          // most complex elements of a workgroup's LDS tile (transformed in place)
+constexpr int A_EPT = A_BUF / A_THREADS;             // elements a thread holds across the barrier of an in-place stage
 constexpr int A_SMOOTH = 127;                        // largest prime factor the Stockham stages are given
 constexpr int64_t A_CHUNK_ELEMS = (int64_t)1 << 25;  // complex elements per scratch buffer (512 MiB)
 constexpr int A_MAX_LOG2_M = 24;                     // longest Bluestein / four-step length: 4096 * 4096
@@ -59,17 +60,17 @@ __global__ void anyn_table_kernel(cplx* __restrict__ tw, int n) { // w_n^m (exac
 template <bool INV>
 __global__ void __launch_bounds__(A_THREADS) anyn_lines_fft(cplx* __restrict__ data, int64_t nlines, LinePlan p, int LP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cplx* cur = reinterpret_cast<cplx*>(smem);
-    cplx* oth = cur + A_BUF;
+    const LdsLine cur(smem);
     const int n = p.n;
     const int64_t l0 = (int64_t)blockIdx.x * LP;
     const int nl = (int)(nlines - l0 < LP ? nlines - l0 : LP);
     cplx* d = data + l0 * n;
     const int tot = nl * n;
+#pragma unroll 4
     for (int w = threadIdx.x; w < tot; w += blockDim.x) cur[w] = d[w];
     __syncthreads();
-    const cplx* res = fft_lines_lds<INV>(cur, oth, p, nl, 1, n);
-    for (int w = threadIdx.x; w < tot; w += blockDim.x) d[w] = res[w];
+    fft_lines_lds_ip<INV, A_EPT, const cplx*>(cur, p, p.tw, nl, 1, n, nullptr, fastdiv_magic((unsigned)nl));
+    for (int w = threadIdx.x; w < tot; w += blockDim.x) d[w] = cur[w];
 }
 
 // four-step, the strided step: every line is an n1 x n2 matrix; n1-point transforms down TC adjacent columns per
@@ -78,8 +79,7 @@ template <bool INV>
 __global__ void __launch_bounds__(A_THREADS) anyn_cols_fft(cplx* __restrict__ data, LinePlan p1, int n2, int TC, int TCs,
                                                            int ntile) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cplx* cur = reinterpret_cast<cplx*>(smem);
-    cplx* oth = cur + A_BUF + 16;
+    const LdsLine cur(smem);
     const int n1 = p1.n;
     const int64_t n = (int64_t)n1 * n2;
     const int64_t line = blockIdx.x / ntile;
@@ -95,10 +95,10 @@ __global__ void __launch_bounds__(A_THREADS) anyn_cols_fft(cplx* __restrict__ da
         cur[k * TCs + c] = v;
     }
     __syncthreads();
-    const cplx* res = fft_lines_lds<INV>(cur, oth, p1, nc, TCs, 1);
+    fft_lines_lds_ip<INV, A_EPT, const cplx*>(cur, p1, p1.tw, nc, TCs, 1, nullptr, fastdiv_magic((unsigned)nc));
     for (int w = threadIdx.x; w < tot; w += blockDim.x) {
         const int k = w / nc, c = w - k * nc;
-        cplx v = res[k * TCs + c];
+        cplx v = cur[k * TCs + c];
         if (!INV) v = cmul(v, unit_root((int64_t)k * (j0 + c), n, false));
         d[(int64_t)k * n2 + j0 + c] = v;
     }
@@ -465,7 +465,7 @@ hipError_t make_fft(gpt_anyn* s, int n, Fft& f, hipStream_t st) {
 
 hipError_t raise_lds(gpt_anyn* s) {
     if (s->lds_raised) return hipSuccess;
-    const int a = 2 * A_BUF * (int)sizeof(cplx), b = 2 * (A_BUF + 16) * (int)sizeof(cplx);
+    const int a = A_BUF * (int)sizeof(cplx), b = A_BUF * (int)sizeof(cplx);
     A_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&anyn_lines_fft<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, a));
     A_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&anyn_lines_fft<true>),
@@ -485,7 +485,7 @@ hipError_t lines_fft(const LinePlan& p, cplx* data, int64_t nlines, bool inv, hi
     if (gpt_pow2_line_fft_supported(p.n)) return gpt_pow2_line_fft(p.n, inv, data, nlines, p.tw, st);
     const int LP = A_BUF / p.n > 1 ? A_BUF / p.n : 1;
     const dim3 grid((unsigned)((nlines + LP - 1) / LP));
-    const size_t lds = 2 * (size_t)A_BUF * sizeof(cplx);
+    const size_t lds = (size_t)LP * p.n * sizeof(cplx); // (the tile itself: short lines leave room for more workgroups)
     if (inv) hipLaunchKernelGGL(anyn_lines_fft<true>, grid, dim3(A_THREADS), lds, st, data, nlines, p, LP);
     else hipLaunchKernelGGL(anyn_lines_fft<false>, grid, dim3(A_THREADS), lds, st, data, nlines, p, LP);
     return hipGetLastError();
@@ -495,14 +495,10 @@ hipError_t cols_fft(const Fft& f, cplx* data, int64_t nlines, bool inv, hipStrea
     int TC = A_BUF / f.n1; // as many adjacent columns as the buffer holds: a short first factor gets a wide tile
     if (TC < 1) TC = 1;
     if (TC > f.n2) TC = f.n2;
-    int TCs = TC | 1;
-    while ((int64_t)f.n1 * TCs > A_BUF && TC > 1) {
-        TC -= 1;
-        TCs = TC | 1;
-    }
+    const int TCs = TC; // (no padding: the stages number their work items across the columns, see gpt_generic.hip)
     const int ntile = (f.n2 + TC - 1) / TC;
     const dim3 grid((unsigned)(nlines * ntile));
-    const size_t lds = 2 * (size_t)(A_BUF + 16) * sizeof(cplx);
+    const size_t lds = (size_t)f.n1 * TCs * sizeof(cplx);
     if (inv) hipLaunchKernelGGL(anyn_cols_fft<true>, grid, dim3(A_THREADS), lds, st, data, f.p1, f.n2, TC, TCs, ntile);
     else hipLaunchKernelGGL(anyn_cols_fft<false>, grid, dim3(A_THREADS), lds, st, data, f.p1, f.n2, TC, TCs, ntile);
     return hipGetLastError();

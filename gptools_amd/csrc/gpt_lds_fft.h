@@ -421,8 +421,10 @@ __device__ __forceinline__ void stage_lds_ip_prime(const LdsLine buf, TWP ptw, c
 template <bool INVERSE, int EPT, typename TWP>
 __device__ __forceinline__ void fft_lines_lds_ip(const LdsLine buf, const LinePlan& p, TWP ptw, int nlines, int es, int ls,
                                                  const StageK* stages, unsigned mL) {
+    int Ns = 1;
     for (int s = 0; s < p.ns; ++s) {
-        const StageK sk = stages[s];
+        const StageK sk = stages ? stages[s] : stage_consts(p.n, p.r[s], Ns); // (null: worked out here, gpt_anyn.hip)
+        Ns *= sk.R;
         switch (sk.R) {
         case 2: stage_lds_ip<2, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
         case 3: stage_lds_ip<3, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
