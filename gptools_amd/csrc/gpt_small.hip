@@ -273,13 +273,20 @@ hipError_t launch_small_t(const LatArgs& a, int cap, int sS, int nthreads, size_
 
 bool gpt_small_fits(int H, int W, int* cap_out, int* stride_out) {
     const int NC = 1 + (W - 1) / 2;
-    const int sS = NC | 1; // odd stride: column walks hit distinct LDS banks
     const int Hp = (H + 1) / 2;
-    int64_t cap = (int64_t)Hp * W;
-    if ((int64_t)H * sS > cap) cap = (int64_t)H * sS;
-    if (cap_out) *cap_out = (int)cap;
-    if (stride_out) *stride_out = sS;
-    return GPT_SMALL_HDR + 2 * cap * (int64_t)sizeof(cplx) <= 160 * 1024;
+    // odd stride between the rows of the packed spectrum (column walks along a line hit distinct LDS banks) where it
+    // fits; the bare NC where only that fits -- 100 x 100: 5100 elements against 5000, the difference between this
+    // kernel and three launches of the generic path (the stages number their work items across the columns, so an even
+    // stride costs the split / merge / packed-column loops a bank conflict, not the transforms)
+    for (int pad = 1; pad >= 0; --pad) {
+        const int sS = pad ? (NC | 1) : NC;
+        int64_t cap = (int64_t)Hp * W;
+        if ((int64_t)H * sS > cap) cap = (int64_t)H * sS;
+        if (cap_out) *cap_out = (int)cap;
+        if (stride_out) *stride_out = sS;
+        if (GPT_SMALL_HDR + 2 * cap * (int64_t)sizeof(cplx) <= 160 * 1024) return true;
+    }
+    return false;
 }
 
 int gpt_small_threads(int H, int W, int64_t batch) {

@@ -33,6 +33,8 @@ def test_path_selection_needs_no_gpu():
     assert lib.gpt_version().decode().startswith("gptools_hip")
     assert lib.gpt_path_for_shape(35, 60) == 0  # docs/trees lattice: one workgroup per lattice
     assert lib.gpt_path_for_shape(1, 128) == 0
+    assert lib.gpt_path_for_shape(100, 100) == 0  # fits one workgroup's LDS without the stride padding only
+    assert lib.gpt_path_for_shape(102, 100) == 2
     assert lib.gpt_path_for_shape(0, 5) == -1
     assert lib.gpt_path_for_shape(65536, 65536) == -1  # n exceeds the reference's 32-bit int
     # any-length path: long series, long or prime axes (four-step / Bluestein line transforms)

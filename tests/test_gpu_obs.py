@@ -56,7 +56,7 @@ def _check(res, want, has_theta):
 
 
 # small-lattice path, generic path (odd sizes), power-of-two path (fused rows, whole-column and sub-line variants); the trees docs shape is 50 x 25 padded to 60 x 35
-@pytest.mark.parametrize("shape,window", [((35, 60), (25, 50)), ((6, 8), (6, 8)), ((7, 9), (3, 4)),
+@pytest.mark.parametrize("shape,window", [((35, 60), (25, 50)), ((6, 8), (6, 8)), ((7, 9), (3, 4)), ((100, 100), (90, 70)),
                                           ((256, 512), (200, 300)), ((300, 210), (150, 210)),
                                           ((1024, 512), (700, 300)), ((512, 2048), (512, 2048))])
 @pytest.mark.parametrize("family", list(FAMILIES))
@@ -282,7 +282,7 @@ def test_obs_host_entry_point(fft, layout):
 
 # ---- the same density from kernel parameters (inverse-transform half) --------------------------------
 @pytest.mark.parametrize("shape,window", [((35, 60), (25, 50)), ((64, 64), (64, 64)), ((7, 9), (3, 4)), ((300, 210), (150, 210)),
-                                          ((256, 256), (200, 100)), ((100,), (80,)), ((128,), (128,))], ids=str)
+                                          ((256, 256), (200, 100)), ((100, 100), (90, 70)), ((100,), (80,)), ((128,), (128,))], ids=str)
 @pytest.mark.parametrize("family", ["neg_binomial_2_log", "normal", "poisson_log"])
 @pytest.mark.parametrize("kind,nu", [("matern", 1.5), ("matern", 2.5), ("matern", 0.9), ("expquad", 0.0)])
 def test_obs_lpdf_kernel_vjp(fft, shape, window, family, kind, nu):

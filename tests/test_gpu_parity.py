@@ -102,7 +102,8 @@ def test_kernels_golden(fft):
         close(fft.gp_periodic_matern_cov_rfft(2.5, n, sigma, l1, p1), g[f"c{idx}_matern52_1"])
 
 
-GRAD_SHAPES = [(5, 7), (5, 8), (6, 7), (6, 8), (2, 2), (3, 2), (2, 3), (1, 8), (1, 7), (35, 60), (64, 64), (27, 25)]
+GRAD_SHAPES = [(5, 7), (5, 8), (6, 7), (6, 8), (2, 2), (3, 2), (2, 3), (1, 8), (1, 7), (35, 60), (64, 64), (27, 25),
+               (100, 100)]  # (the largest square the one-workgroup kernel takes: only without its LDS stride padding)
 
 
 @pytest.mark.parametrize("shape", GRAD_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
@@ -435,7 +436,7 @@ def test_subline_path_variants(fft):
         fft.gp_rfft2_lpdf_vjp(y, loc, bad)
 
 
-@pytest.mark.parametrize("shape", [(1024, 1024), (512, 2048), (35, 60), (128,)], ids=str)
+@pytest.mark.parametrize("shape", [(1024, 1024), (512, 2048), (35, 60), (100, 100), (128,)], ids=str)
 @pytest.mark.parametrize("kind,nu", [("matern", 1.5), ("matern", 2.5), ("matern", 0.9), ("expquad", 0.0)])
 def test_kernel_fused_lpdf(fft, shape, kind, nu):
     """gp_rfft2_lpdf over gp_periodic_*_cov_rfft2 + nugget without the spectrum in memory (power-of-two lattices of
