@@ -135,13 +135,34 @@ int run_units(gpt_ctx* c, int op, const LatArgs& a, int path, int64_t chunk, cpl
     return GPT_OK;
 }
 
+// A lattice that fills more than half of a CU's LDS runs one workgroup per CU on the one-workgroup path: fine for a few
+// chains (one launch, ~30 us), but a launch of many such lattices is then one latency-bound workgroup after the other on
+// every CU, and the generic three-pass path (several small workgroups per CU) has the higher throughput.
+// Measured (profiles/r03_s_small_vs_generic_many.jsonl, value + gradients, us per launch, one-workgroup / generic):
+// 72 x 72: 256 chains 29.6 / 45.2, 1024 chains 178 / 119, 4096 chains 803 / 474; 96 x 100: 40.9 / 65.9, 273 / 204, 1266 / 830
+// -- up to one lattice per CU the single launch wins, from four per CU the three passes do by 1.3 - 1.7x.
+// GPT_SMALL_TO_GENERIC_BATCH=<n>: lattices per launch from which such lattices take the generic path (default 768 = three
+// per CU; 0 = never).
+static bool many_large_small_lattices(int op, const LatArgs& a) {
+    static const int64_t from = [] {
+        const char* e = getenv("GPT_SMALL_TO_GENERIC_BATCH");
+        return (int64_t)(e ? atol(e) : 768);
+    }();
+    if (from <= 0 || a.batch < from || a.dim1 || op_is_kvjp(op)) return false;
+    if (a.H < 32 || a.W < 32 || !gpt_generic_supported(a.H, a.W)) return false;
+    int cap = 0;
+    if (!gpt_small_fits(a.H, a.W, &cap, nullptr)) return false;
+    return 2 * (size_t)cap * sizeof(cplx) > 80 * 1024;
+}
+
 int run_lattice(gpt_ctx* c, int op, LatArgs a) {
     const bool armed = c->done_armed; // (one request, one launch: whatever happens below, it does not outlive this call)
     c->done_armed = false;
     HIP_TRY(c, hipSetDevice(c->device));
     if (a.batch == 0) return GPT_OK;
     int rc;
-    const int path = path_for_shape(a.H, a.W);
+    int path = path_for_shape(a.H, a.W);
+    if (path == 0 && many_large_small_lattices(op, a)) path = 2;
     if (path == 3) { // any-length path: its own plans (four-step / Bluestein), tables and scratch
         if (!c->anyn) c->anyn = gpt_anyn_create();
         return run_units(c, op, a, path, gpt_anyn_chunk(a.H, a.W), nullptr, nullptr, false);

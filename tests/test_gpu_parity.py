@@ -363,6 +363,33 @@ def test_three_pass_path_vs_oracle(fft, shape):
         fft.gp_rfft2_lpdf(y, loc, bad)
 
 
+def test_many_large_one_workgroup_lattices_take_the_generic_path(fft):
+    """Lattices that fill more than half a CU's LDS on the one-workgroup path go to the generic three-pass path when a
+    launch holds 768 or more of them (gpt_api.hip many_large_small_lattices): same results as the same lattices in small
+    launches, and as the oracle."""
+    h, w, b = 72, 72, 800
+    rng = np.random.default_rng(72800)
+    y = rng.normal(size=(b, h, w))
+    loc = rng.normal(size=(h, w))
+    cov = np.exp(0.3 * rng.normal(size=(b, h, w // 2 + 1)))
+    lp, gy, gc = fft.gp_rfft2_lpdf_vjp(y, loc, cov)
+    for lo in (0, 400, 790):
+        lp_s, gy_s, gc_s = fft.gp_rfft2_lpdf_vjp(y[lo:lo + 10], loc, cov[lo:lo + 10])  # (one workgroup per lattice)
+        close(lp[lo:lo + 10], lp_s.cpu())
+        close(gy[lo:lo + 10], gy_s.cpu())
+        close(gc[lo:lo + 10], gc_s.cpu())
+    for i in (0, 799):
+        lp_o, gy_o, gc_o = o.gp_rfft2_lpdf_vjp(y[i], loc, cov[i])
+        close(lp[i], lp_o)
+        close(gy[i], gy_o)
+        close(gc[i], gc_o)
+    z = rng.normal(size=(b, h, w))
+    f = fft.gp_inv_rfft2(z, loc, cov)
+    close(f[:4], fft.gp_inv_rfft2(z[:4], loc, cov[:4]).cpu())
+    close(f[799], o.gp_inv_rfft2(z[799], loc, cov[799]))
+    close(fft.gp_rfft2(y, loc, cov)[795:], o.gp_rfft2(y[795:], loc, cov[795:]))
+
+
 def test_headline_shape_4096(fft):
     """BASELINE config 4 (4096 x 4096): value and gradients against the oracle on one lattice, plus
     size-independent properties: transform round trip and linearity of the gradient in (y - loc)."""
