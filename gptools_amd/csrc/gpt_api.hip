@@ -54,8 +54,19 @@ int plan_radices(gpt_ctx* c, int n, LinePlan& p, bool wide) {
         p.ns++;
     };
     if (wide) {
-        while (m % 16 == 0) { push(16); m /= 16; }
-        if (m % 8 == 0) { push(8); m /= 8; }
+        // 5-smooth lengths (what a padded lattice usually is) keep to radices 8, 4, 2, 3, 5: their kernels are the lean
+        // instantiations of gpt_generic.hip (half the registers, twice the waves per SIMD); anything else takes
+        // radix-16 steps first
+        int odd = n;
+        while (odd % 2 == 0) odd /= 2;
+        while (odd % 3 == 0) odd /= 3;
+        while (odd % 5 == 0) odd /= 5;
+        if (odd == 1) {
+            while (m % 8 == 0) { push(8); m /= 8; }
+        } else {
+            while (m % 16 == 0) { push(16); m /= 16; }
+            if (m % 8 == 0) { push(8); m /= 8; }
+        }
     }
     while (m % 4 == 0) { push(4); m /= 4; }
     while (m % 2 == 0) { push(2); m /= 2; }

@@ -133,7 +133,7 @@ __device__ __forceinline__ double g_in(const LatArgs& a, int64_t b, int i, int j
     return v;
 }
 
-template <int IN_MODE>
+template <int IN_MODE, bool LEAN>
 __global__ void __launch_bounds__(G_THREADS) g_row_fwd(LatArgs a, GenGeo g, GenStages st, cplx* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLine cur(smem); // (LDS-typed handle, gpt_lds_fft.h)
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(G_THREADS) g_row_fwd(LatArgs a, GenGeo g, GenS
         cur[w] = make_double2(re, im);
     }
     __syncthreads();
-    fft_lines_lds_ip<false, G_EPT, const cplx*>(cur, a.pw, a.pw.tw, nl, 1, W, st.s, nl == g.LP ? g.mLP : g.mLPtail);
+    fft_lines_lds_ip<false, G_EPT, const cplx*, LEAN>(cur, a.pw, a.pw.tw, nl, 1, W, st.s, nl == g.LP ? g.mLP : g.mLPtail);
     const LdsLine res = cur;
     cplx* wsb = ws + (int64_t)b * H * g.wstride;
     for (int w = threadIdx.x; w < 2 * nl * g.NC; w += blockDim.x) {
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(G_THREADS) g_row_fwd(LatArgs a, GenGeo g, GenS
     }
 }
 
-template <int OP>
+template <int OP, bool LEAN>
 __global__ void __launch_bounds__(G_COL_THREADS_MAX) g_col(LatArgs a, GenGeo g, GenStages st, cplx* __restrict__ ws,
                                                     double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(G_COL_THREADS_MAX) g_col(LatArgs a, GenGeo g, 
         }
         __syncthreads();
         GMARK(1);
-        fft_lines_lds_ip<false, G_EPT, const cplx*>(cur, a.ph, a.ph.tw, nc, sS, 1, st.s, mnc);
+        fft_lines_lds_ip<false, G_EPT, const cplx*, LEAN>(cur, a.ph, a.ph.tw, nc, sS, 1, st.s, mnc);
     }
     GMARK(2);
     EwAcc acc;
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(G_COL_THREADS_MAX) g_col(LatArgs a, GenGeo g, 
     __syncthreads();
     GMARK(3);
     if (op_has_inv(OP)) {
-        fft_lines_lds_ip<true, G_EPT, const cplx*>(cur, a.ph, a.ph.tw, nc, sS, 1, st.s, mnc);
+        fft_lines_lds_ip<true, G_EPT, const cplx*, LEAN>(cur, a.ph, a.ph.tw, nc, sS, 1, st.s, mnc);
         const LdsLine res = cur;
         GMARK(4);
         for (int w = threadIdx.x; w < H * nc; w += blockDim.x) {
@@ -275,6 +275,7 @@ __global__ void __launch_bounds__(G_COL_THREADS_MAX) g_col(LatArgs a, GenGeo g, 
     }
 }
 
+template <bool LEAN>
 __global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, GenStages st, double alpha, int add_loc,
                                                        const cplx* __restrict__ ws, FinArgs fin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -304,7 +305,7 @@ __global__ void __launch_bounds__(G_THREADS) g_row_inv(LatArgs a, GenGeo g, GenS
         cur[w] = make_double2(A.x - B.y, A.y + B.x);
     }
     __syncthreads();
-    fft_lines_lds_ip<true, G_EPT, const cplx*>(cur, a.pw, a.pw.tw, nl, 1, W, st.s, nl == g.LP ? g.mLP : g.mLPtail);
+    fft_lines_lds_ip<true, G_EPT, const cplx*, LEAN>(cur, a.pw, a.pw.tw, nl, 1, W, st.s, nl == g.LP ? g.mLP : g.mLPtail);
     const LdsLine res = cur;
     double* ob = a.out + b * (int64_t)H * W;
     for (int w = threadIdx.x; w < nl * W; w += blockDim.x) {
@@ -338,26 +339,48 @@ hipError_t raise_lds_cap(const void* kernel, std::atomic<uint64_t>& done, int by
     return e;
 }
 
-template <int OP>
-hipError_t launch_col(const LatArgs& a, const GenGeo& g, cplx* ws, double* partials, int nblk, hipStream_t st) {
+template <int OP, bool LEAN>
+hipError_t launch_col_t(const LatArgs& a, const GenGeo& g, cplx* ws, double* partials, int nblk, hipStream_t st) {
     const size_t lds = 512 + ((size_t)a.H * g.TCs + 16) * sizeof(cplx);
     static std::atomic<uint64_t> done{0};
-    hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&g_col<OP>), done,
+    hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&g_col<OP, LEAN>), done,
                                  (int)(512 + (size_t)(2 * G_BUF_ELEMS + 16) * sizeof(cplx)));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(g_col<OP>, dim3(nblk, (unsigned)a.batch), dim3(g.cthreads), lds, st, a, g, make_stages(a.ph), ws,
-                       partials);
+    hipLaunchKernelGGL((g_col<OP, LEAN>), dim3(nblk, (unsigned)a.batch), dim3(g.cthreads), lds, st, a, g, make_stages(a.ph),
+                       ws, partials);
     return hipGetLastError();
 }
+// (the lean instantiation where the column plan allows it: see fft_lines_lds_ip)
+template <int OP>
+hipError_t launch_col(const LatArgs& a, const GenGeo& g, cplx* ws, double* partials, int nblk, hipStream_t st) {
+    return lean_plan(a.ph) ? launch_col_t<OP, true>(a, g, ws, partials, nblk, st)
+                           : launch_col_t<OP, false>(a, g, ws, partials, nblk, st);
+}
 
-template <int IN_MODE> hipError_t launch_row_fwd(const LatArgs& a, const GenGeo& g, cplx* ws, hipStream_t st) {
+template <int IN_MODE, bool LEAN> hipError_t launch_row_fwd_t(const LatArgs& a, const GenGeo& g, cplx* ws, hipStream_t st) {
     const size_t lds = (size_t)g.LP * a.W * sizeof(cplx);
     static std::atomic<uint64_t> done{0};
-    hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&g_row_fwd<IN_MODE>), done,
+    hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&g_row_fwd<IN_MODE, LEAN>), done,
                                  (int)((size_t)G_BUF_ELEMS * sizeof(cplx)));
     if (e != hipSuccess) return e;
     const int nb = (g.Hp + g.LP - 1) / g.LP;
-    hipLaunchKernelGGL(g_row_fwd<IN_MODE>, dim3(nb, (unsigned)a.batch), dim3(g.rthreads), lds, st, a, g, make_stages(a.pw), ws);
+    hipLaunchKernelGGL((g_row_fwd<IN_MODE, LEAN>), dim3(nb, (unsigned)a.batch), dim3(g.rthreads), lds, st, a, g,
+                       make_stages(a.pw), ws);
+    return hipGetLastError();
+}
+template <int IN_MODE> hipError_t launch_row_fwd(const LatArgs& a, const GenGeo& g, cplx* ws, hipStream_t st) {
+    return lean_plan(a.pw) ? launch_row_fwd_t<IN_MODE, true>(a, g, ws, st) : launch_row_fwd_t<IN_MODE, false>(a, g, ws, st);
+}
+template <bool LEAN>
+hipError_t launch_row_inv_t(const LatArgs& a, const GenGeo& g, double alpha, int add_loc, const cplx* ws, const FinArgs& fin,
+                            hipStream_t st) {
+    const size_t lds = (size_t)g.LP * a.W * sizeof(cplx);
+    static std::atomic<uint64_t> done{0};
+    hipError_t e = raise_lds_cap(reinterpret_cast<const void*>(&g_row_inv<LEAN>), done, (int)((size_t)G_BUF_ELEMS * sizeof(cplx)));
+    if (e != hipSuccess) return e;
+    const int nb = (g.Hp + g.LP - 1) / g.LP;
+    hipLaunchKernelGGL(g_row_inv<LEAN>, dim3(nb, (unsigned)a.batch), dim3(g.rthreads), lds, st, a, g, make_stages(a.pw), alpha,
+                       add_loc, ws, fin);
     return hipGetLastError();
 }
 
@@ -417,14 +440,8 @@ hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partia
         if (op == OP_INV_RFFT2) alpha = 1.0 / n;
         else if (op == OP_GP_INV_RFFT2) { alpha = 1.0 / n; add_loc = 1; }
         else if (op_is_lpdf_vjp(op)) alpha = -1.0 / n;
-        const size_t lds = (size_t)g.LP * a.W * sizeof(cplx);
-        static std::atomic<uint64_t> done{0};
-        e = raise_lds_cap(reinterpret_cast<const void*>(&g_row_inv), done, (int)((size_t)G_BUF_ELEMS * sizeof(cplx)));
-        if (e != hipSuccess) return e;
-        const int nb = (g.Hp + g.LP - 1) / g.LP;
-        hipLaunchKernelGGL(g_row_inv, dim3(nb, (unsigned)a.batch), dim3(g.rthreads), lds, st, a, g, make_stages(a.pw), alpha,
-                           add_loc, ws, fin);
-        e = hipGetLastError();
+        e = lean_plan(a.pw) ? launch_row_inv_t<true>(a, g, alpha, add_loc, ws, fin, st)
+                            : launch_row_inv_t<false>(a, g, alpha, add_loc, ws, fin, st);
     }
     return e;
 }

@@ -417,8 +417,12 @@ __device__ __forceinline__ void stage_lds_ip_prime(const LdsLine buf, TWP ptw, c
 }
 
 // all the stages of plan `p` over `nlines` lines of `buf`, in place (stage constants and the magic of nlines from the host);
-// the caller's data must be visible (a barrier) before the call, the result is visible to the whole workgroup after it
-template <bool INVERSE, int EPT, typename TWP>
+// the caller's data must be visible (a barrier) before the call, the result is visible to the whole workgroup after it.
+// LEAN: the instantiation for plans of radices 2, 3, 4, 5 and 8 only (lean_plan below: what a 5-smooth length gets) --
+// a kernel's registers are the maximum over every stage it COULD run, and the radix-7 / 11 / 13 / 16 / any-prime stages
+// are what that maximum is: 117 - 127 registers for the generic row kernels with them, 64 - 68 without (8 waves per SIMD
+// instead of 4), 128 with 10 - 22 spilled against 86 - 96 for the column kernel.
+template <bool INVERSE, int EPT, typename TWP, bool LEAN = false>
 __device__ __forceinline__ void fft_lines_lds_ip(const LdsLine buf, const LinePlan& p, TWP ptw, int nlines, int es, int ls,
                                                  const StageK* stages, unsigned mL) {
     int Ns = 1;
@@ -430,14 +434,28 @@ __device__ __forceinline__ void fft_lines_lds_ip(const LdsLine buf, const LinePl
         case 3: stage_lds_ip<3, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
         case 4: stage_lds_ip<4, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
         case 5: stage_lds_ip<5, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
-        case 7: stage_lds_ip<7, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
         case 8: stage_lds_ip<8, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
-        case 11: stage_lds_ip<11, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
-        case 13: stage_lds_ip<13, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
-        case 16: stage_lds_ip<16, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
-        default: stage_lds_ip_prime<INVERSE, EPT, TWP>(buf, ptw, sk, p.n, nlines, mL, es, ls); break;
+        default:
+            if constexpr (!LEAN) {
+                switch (sk.R) {
+                case 7: stage_lds_ip<7, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+                case 11: stage_lds_ip<11, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+                case 13: stage_lds_ip<13, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+                case 16: stage_lds_ip<16, INVERSE, EPT, TWP>(buf, ptw, sk, nlines, mL, es, ls); break;
+                default: stage_lds_ip_prime<INVERSE, EPT, TWP>(buf, ptw, sk, p.n, nlines, mL, es, ls); break;
+                }
+            }
+            break;
         }
     }
+}
+
+__host__ __device__ inline bool lean_plan(const LinePlan& p) {
+    for (int s = 0; s < p.ns; ++s) {
+        const int r = p.r[s];
+        if (!(r == 2 || r == 3 || r == 4 || r == 5 || r == 8)) return false;
+    }
+    return true;
 }
 
 // twiddles where the plan has them (global memory)
