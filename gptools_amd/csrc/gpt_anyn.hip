@@ -57,7 +57,7 @@ __global__ void anyn_table_kernel(cplx* __restrict__ tw, int n) { // w_n^m (exac
 
 // ---- line transforms ----------------------------------------------------------------------------------
 // contiguous lines of n <= 4096 points, LP lines per workgroup
-template <bool INV>
+template <bool INV, bool LEAN> // LEAN: plans of radices 2, 3, 4, 5, 8 only (gpt_lds_fft.h: half the registers)
 __global__ void __launch_bounds__(A_THREADS) anyn_lines_fft(cplx* __restrict__ data, int64_t nlines, LinePlan p, int LP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLine cur(smem);
@@ -69,13 +69,13 @@ __global__ void __launch_bounds__(A_THREADS) anyn_lines_fft(cplx* __restrict__ d
 #pragma unroll 4
     for (int w = threadIdx.x; w < tot; w += blockDim.x) cur[w] = d[w];
     __syncthreads();
-    fft_lines_lds_ip<INV, A_EPT, const cplx*>(cur, p, p.tw, nl, 1, n, nullptr, fastdiv_magic((unsigned)nl));
+    fft_lines_lds_ip<INV, A_EPT, const cplx*, LEAN>(cur, p, p.tw, nl, 1, n, nullptr, fastdiv_magic((unsigned)nl));
     for (int w = threadIdx.x; w < tot; w += blockDim.x) d[w] = cur[w];
 }
 
 // four-step, the strided step: every line is an n1 x n2 matrix; n1-point transforms down TC adjacent columns per
 // workgroup, with the twiddle w_n^(k1 j2) behind (forward) or its conjugate in front (inverse)
-template <bool INV>
+template <bool INV, bool LEAN>
 __global__ void __launch_bounds__(A_THREADS) anyn_cols_fft(cplx* __restrict__ data, LinePlan p1, int n2, int TC, int TCs,
                                                            int ntile) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(A_THREADS) anyn_cols_fft(cplx* __restrict__ da
         cur[k * TCs + c] = v;
     }
     __syncthreads();
-    fft_lines_lds_ip<INV, A_EPT, const cplx*>(cur, p1, p1.tw, nc, TCs, 1, nullptr, fastdiv_magic((unsigned)nc));
+    fft_lines_lds_ip<INV, A_EPT, const cplx*, LEAN>(cur, p1, p1.tw, nc, TCs, 1, nullptr, fastdiv_magic((unsigned)nc));
     for (int w = threadIdx.x; w < tot; w += blockDim.x) {
         const int k = w / nc, c = w - k * nc;
         cplx v = cur[k * TCs + c];
@@ -434,8 +434,16 @@ hipError_t line_plan(gpt_anyn* s, int n, LinePlan& p, hipStream_t st) {
         if (p.ns < GPT_MAX_STAGES) p.r[p.ns] = r;
         p.ns++;
     };
-    while (m % 16 == 0) { push(16); m /= 16; } // register butterflies: one pass through LDS for four bits
-    if (m % 8 == 0) { push(8); m /= 8; }
+    int odd = n; // 5-smooth lengths keep to radices 8, 4, 2, 3, 5: the lean kernels (as plan_radices, gpt_api.hip)
+    while (odd % 2 == 0) odd /= 2;
+    while (odd % 3 == 0) odd /= 3;
+    while (odd % 5 == 0) odd /= 5;
+    if (odd == 1) {
+        while (m % 8 == 0) { push(8); m /= 8; }
+    } else {
+        while (m % 16 == 0) { push(16); m /= 16; } // register butterflies: one pass through LDS for four bits
+        if (m % 8 == 0) { push(8); m /= 8; }
+    }
     while (m % 4 == 0) { push(4); m /= 4; }
     while (m % 2 == 0) { push(2); m /= 2; }
     for (int f = 3; (int64_t)f * f <= m; f += 2)
@@ -466,14 +474,18 @@ hipError_t make_fft(gpt_anyn* s, int n, Fft& f, hipStream_t st) {
 hipError_t raise_lds(gpt_anyn* s) {
     if (s->lds_raised) return hipSuccess;
     const int a = A_BUF * (int)sizeof(cplx), b = A_BUF * (int)sizeof(cplx);
-    A_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&anyn_lines_fft<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, a));
-    A_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&anyn_lines_fft<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, a));
-    A_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&anyn_cols_fft<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, b));
-    A_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&anyn_cols_fft<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, b));
+    const void* lines[4] = {reinterpret_cast<const void*>(&anyn_lines_fft<false, false>),
+                            reinterpret_cast<const void*>(&anyn_lines_fft<true, false>),
+                            reinterpret_cast<const void*>(&anyn_lines_fft<false, true>),
+                            reinterpret_cast<const void*>(&anyn_lines_fft<true, true>)};
+    const void* cols[4] = {reinterpret_cast<const void*>(&anyn_cols_fft<false, false>),
+                           reinterpret_cast<const void*>(&anyn_cols_fft<true, false>),
+                           reinterpret_cast<const void*>(&anyn_cols_fft<false, true>),
+                           reinterpret_cast<const void*>(&anyn_cols_fft<true, true>)};
+    for (int i = 0; i < 4; ++i) {
+        A_TRY(hipFuncSetAttribute(lines[i], hipFuncAttributeMaxDynamicSharedMemorySize, a));
+        A_TRY(hipFuncSetAttribute(cols[i], hipFuncAttributeMaxDynamicSharedMemorySize, b));
+    }
     s->lds_raised = true;
     return hipSuccess;
 }
@@ -486,8 +498,11 @@ hipError_t lines_fft(const LinePlan& p, cplx* data, int64_t nlines, bool inv, hi
     const int LP = A_BUF / p.n > 1 ? A_BUF / p.n : 1;
     const dim3 grid((unsigned)((nlines + LP - 1) / LP));
     const size_t lds = (size_t)LP * p.n * sizeof(cplx); // (the tile itself: short lines leave room for more workgroups)
-    if (inv) hipLaunchKernelGGL(anyn_lines_fft<true>, grid, dim3(A_THREADS), lds, st, data, nlines, p, LP);
-    else hipLaunchKernelGGL(anyn_lines_fft<false>, grid, dim3(A_THREADS), lds, st, data, nlines, p, LP);
+    const bool lean = lean_plan(p);
+    if (inv && lean) hipLaunchKernelGGL((anyn_lines_fft<true, true>), grid, dim3(A_THREADS), lds, st, data, nlines, p, LP);
+    else if (inv) hipLaunchKernelGGL((anyn_lines_fft<true, false>), grid, dim3(A_THREADS), lds, st, data, nlines, p, LP);
+    else if (lean) hipLaunchKernelGGL((anyn_lines_fft<false, true>), grid, dim3(A_THREADS), lds, st, data, nlines, p, LP);
+    else hipLaunchKernelGGL((anyn_lines_fft<false, false>), grid, dim3(A_THREADS), lds, st, data, nlines, p, LP);
     return hipGetLastError();
 }
 
@@ -499,8 +514,11 @@ hipError_t cols_fft(const Fft& f, cplx* data, int64_t nlines, bool inv, hipStrea
     const int ntile = (f.n2 + TC - 1) / TC;
     const dim3 grid((unsigned)(nlines * ntile));
     const size_t lds = (size_t)f.n1 * TCs * sizeof(cplx);
-    if (inv) hipLaunchKernelGGL(anyn_cols_fft<true>, grid, dim3(A_THREADS), lds, st, data, f.p1, f.n2, TC, TCs, ntile);
-    else hipLaunchKernelGGL(anyn_cols_fft<false>, grid, dim3(A_THREADS), lds, st, data, f.p1, f.n2, TC, TCs, ntile);
+    const bool lean = lean_plan(f.p1);
+    if (inv && lean) hipLaunchKernelGGL((anyn_cols_fft<true, true>), grid, dim3(A_THREADS), lds, st, data, f.p1, f.n2, TC, TCs, ntile);
+    else if (inv) hipLaunchKernelGGL((anyn_cols_fft<true, false>), grid, dim3(A_THREADS), lds, st, data, f.p1, f.n2, TC, TCs, ntile);
+    else if (lean) hipLaunchKernelGGL((anyn_cols_fft<false, true>), grid, dim3(A_THREADS), lds, st, data, f.p1, f.n2, TC, TCs, ntile);
+    else hipLaunchKernelGGL((anyn_cols_fft<false, false>), grid, dim3(A_THREADS), lds, st, data, f.p1, f.n2, TC, TCs, ntile);
     return hipGetLastError();
 }
 
