@@ -148,22 +148,26 @@ int run_units(gpt_ctx* c, int op, const LatArgs& a, int path, int64_t chunk, cpl
 
 // A lattice that fills more than half of a CU's LDS runs one workgroup per CU on the one-workgroup path: fine for a few
 // chains (one launch, ~30 us), but a launch of many such lattices is then one latency-bound workgroup after the other on
-// every CU, and the generic three-pass path (several small workgroups per CU) has the higher throughput.
+// every CU, and the generic three-pass path (several small workgroups per CU, lean kernels) has the higher throughput.
 // Measured (profiles/r03_s_small_vs_generic_many.jsonl, value + gradients, us per launch, one-workgroup / generic):
-// 72 x 72: 256 chains 29.6 / 45.2, 1024 chains 178 / 119, 4096 chains 803 / 474; 96 x 100: 40.9 / 65.9, 273 / 204, 1266 / 830
-// -- up to one lattice per CU the single launch wins, from four per CU the three passes do by 1.3 - 1.7x.
-// GPT_SMALL_TO_GENERIC_BATCH=<n>: lattices per launch from which such lattices take the generic path (default 768 = three
-// per CU; 0 = never).
+//   72 x 72 (83 KB):  256 chains 29.5 / 43.1, 384: 54.4 / 49.7, 512: 89.8 / 56.1, 1024: 177 / 94.6, 4096: 801 / 359
+//   96 x 100 (150 KB): 256: 40.4 / 51.6, 384: 74.9 / 68.5, 512: 137 / 83.9, 4096: 1266 / 648
+//   60 x 60 (58 KB, two workgroups per CU): 512: 37.7 / 46.7, 1024: 72.9 / 67.7, 4096: 333 / 261
+//   50 x 50 (40 KB) and smaller, 35 x 60: the one-workgroup path at every count (4096: 154 / 219, 121 / 200)
+// -- up to a lattice per CU the single launch wins; from 1.5 per CU (one workgroup per CU) or 8 per CU (two) the three
+// passes do. GPT_SMALL_TO_GENERIC_BATCH=<n>: that first count (default 384; 0 = never re-route).
 static bool many_large_small_lattices(int op, const LatArgs& a) {
     static const int64_t from = [] {
         const char* e = getenv("GPT_SMALL_TO_GENERIC_BATCH");
-        return (int64_t)(e ? atol(e) : 768);
+        return (int64_t)(e ? atol(e) : 384);
     }();
     if (from <= 0 || a.batch < from || a.dim1 || op_is_kvjp(op)) return false;
     if (a.H < 32 || a.W < 32 || !gpt_generic_supported(a.H, a.W)) return false;
     int cap = 0;
     if (!gpt_small_fits(a.H, a.W, &cap, nullptr)) return false;
-    return 2 * (size_t)cap * sizeof(cplx) > 80 * 1024;
+    const size_t lds = 2 * (size_t)cap * sizeof(cplx);
+    if (lds > 80 * 1024) return true;                      // one workgroup per CU
+    return lds > 160 * 1024 / 3 && a.batch >= 2048;         // two
 }
 
 int run_lattice(gpt_ctx* c, int op, LatArgs a) {
