@@ -285,6 +285,36 @@ def fused_kernel_extra(fft, ctx, y, loc, steps):
     return rec
 
 
+def generic_path_extra(fft, device):
+    """NOT the headline: shapes that are neither small nor powers of two (the generic three-pass path, DESIGN 5.3: in-place
+    LDS transforms, lean kernels for 5-smooth sizes) and a launch of many large one-workgroup lattices, which is re-routed
+    to it. gp_rfft2_lpdf + both gradients, device-resident, outputs preallocated, HIP events around the launches."""
+    rec = {}
+    g = torch.Generator(device=device)
+    g.manual_seed(11)
+    for h, w, B in ((1000, 1000, 8), (3000, 3000, 2), (192, 192, 64), (72, 72, 4096)):
+        y = torch.randn(B, h, w, dtype=torch.float64, device=device, generator=g)
+        loc = torch.zeros(h, w, dtype=torch.float64, device=device)
+        cov = torch.exp(0.3 * torch.randn(B, h, w // 2 + 1, dtype=torch.float64, device=device, generator=g))
+        out = (torch.empty(B, dtype=torch.float64, device=device), torch.empty_like(y), torch.empty_like(cov),
+               torch.empty(B, dtype=torch.float64, device=device))
+
+        def lpdf():
+            fft.gp_rfft2_lpdf_vjp(y, loc, cov, check=False, out=out)
+
+        for _ in range(3):
+            lpdf()
+        sec = event_timed(lpdf, 10)
+        b_alg = 24 * h * w + 16 * h * (w // 2 + 1)
+        rec[f"{h}x{w}"] = {"lattices_per_launch": B, "path": fft.path_for_shape(h, w), "us_per_launch": 1e6 * sec,
+                           "us_per_lattice": 1e6 * sec / B, "evals_per_s": B / sec, "achieved_GBps": B * b_alg / sec / 1e9,
+                           "frac": B * b_alg / sec / HBM_PEAK, "finite": bool(torch.isfinite(out[0]).all())}
+        del y, cov, out
+    rec["72x72"]["note"] = "path 0 by shape; launches of >= 384 such lattices run on the generic path (gpt_api.hip)"
+    torch.cuda.empty_cache()
+    return rec
+
+
 def small_lattice_extra(fft, device):
     """NOT the headline: BASELINE configs[0] / [2], the shapes of the reference's own docs models, as a sampler farm
     would run them -- 4096 chains of the 35 x 60 trees lattice per launch (one workgroup per lattice), value +
@@ -592,6 +622,7 @@ def main():
         if world == 1 and not args.no_extra:
             result["extra"] = {"kernel_fused_lpdf": fused_kernel_extra(fft, ctx, y, loc, max(2, min(args.steps, 5))),
                                "docs_shape_35x60": small_lattice_extra(fft, device)}
+            result["extra"]["generic_path"] = generic_path_extra(fft, device)
             # what the roofline fraction means: the same B_alg with nothing shared, and the
             # traffic-only ceiling of the three-pass structure on this box
         if world == 1 and not args.no_extra and not args.no_ceiling:
