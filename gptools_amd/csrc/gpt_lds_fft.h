@@ -421,7 +421,8 @@ __device__ __forceinline__ void stage_lds_ip_prime(const LdsLine buf, TWP ptw, c
 // LEAN: the instantiation for plans of radices 2, 3, 4, 5 and 8 only (lean_plan below: what a 5-smooth length gets) --
 // a kernel's registers are the maximum over every stage it COULD run, and the radix-7 / 11 / 13 / 16 / any-prime stages
 // are what that maximum is: 117 - 127 registers for the generic row kernels with them, 64 - 68 without (8 waves per SIMD
-// instead of 4), 128 with 10 - 22 spilled against 86 - 96 for the column kernel.
+// instead of 4), 128 with 10 - 22 spilled against 86 - 96 for the column kernel. (Radix 7 in the lean set was compiled:
+// +24 registers everywhere -- 88 for the row kernels, 106 - 117 for the column kernel -- so 7-smooth lengths stay full.)
 template <bool INVERSE, int EPT, typename TWP, bool LEAN = false>
 __device__ __forceinline__ void fft_lines_lds_ip(const LdsLine buf, const LinePlan& p, TWP ptw, int nlines, int es, int ls,
                                                  const StageK* stages, unsigned mL) {
