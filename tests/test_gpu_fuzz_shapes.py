@@ -70,3 +70,43 @@ def test_shape_sweep(fft, shape):
     # other on the edge columns, fft2.stan:65,127-128)
     close(fft.gp_rfft2(y, loc, cov), o.gp_rfft2(y, loc, cov))
     close(fft.rfft2(y), o.rfft2(y))
+
+
+def _generic_shapes():
+    """Shapes of the generic three-pass path (gpt_generic.hip): column tiles of 16 / 8 / 4 / 2 / 1 columns with ragged last
+    tiles, tile counts that are and are not multiples of eight (the XCD numbering), workgroups of 128 ... 1024 threads,
+    5-smooth lines (lean kernels) mixed with lines that have factors 7, 11, 13, 16 or a larger prime."""
+    rng = np.random.default_rng(20261111)
+    out = [(1200, 36), (1201, 36), (2400, 18), (4050, 10), (36, 1200), (150, 3000), (1024, 90), (640, 650), (125, 729),
+           (343, 130), (169, 176), (121, 1331), (720, 34), (34, 720), (1999, 14)]
+    def smooth(n, top):  # largest prime factor <= top
+        for f in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43):
+            while f <= top and n % f == 0:
+                n //= f
+        return n == 1
+
+    lens = [n for n in range(100, 1300) if smooth(n, 43)]  # (a prime factor above 127 sends a shape to the any-length path)
+    while len(out) < 60:
+        h, w = int(rng.choice(lens)), int(rng.choice(lens))
+        if h * w <= 900_000:
+            out.append((h, w))
+    return out
+
+
+@pytest.mark.parametrize("shape", _generic_shapes(), ids=lambda s: f"{s[0]}x{s[1]}")
+def test_generic_path_sweep(fft, shape):
+    h, w = shape
+    if fft.path_for_shape(h, w) != 2:
+        pytest.skip("not a generic-path shape")
+    rng = np.random.default_rng(11 * h + 17 * w)
+    nb = 3
+    cov = np.exp(0.4 * rng.normal(size=(nb, h, w // 2 + 1))) + 0.05  # one spectrum per lattice
+    y, loc, z = rng.normal(size=(nb, h, w)), rng.normal(size=(h, w)), rng.normal(size=(nb, h, w))
+    lp, gy, gc = fft.gp_rfft2_lpdf_vjp(y, loc, cov)
+    for b in range(nb):
+        lp_o, gy_o, gc_o = o.gp_rfft2_lpdf_vjp(y[b], loc, cov[b])
+        close(lp[b], lp_o)
+        close(gy[b], gy_o)
+        close(gc[b], gc_o)
+    close(fft.gp_inv_rfft2(z, loc, cov)[nb - 1], o.gp_inv_rfft2(z[nb - 1], loc, cov[nb - 1]))
+    close(fft.gp_rfft2(y, loc, cov)[nb - 1], o.gp_rfft2(y[nb - 1], loc, cov[nb - 1]))
