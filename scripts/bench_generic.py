@@ -23,7 +23,9 @@ def main():
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(3)
     shapes = [(144, 144), (160, 160), (176, 176), (192, 192), (301, 200), (1000, 1000), (3000, 3000)]
-    only = sys.argv[1] if len(sys.argv) > 1 else ""  # "HxW": that shape only
+    only = sys.argv[1] if len(sys.argv) > 1 else ""  # "HxW": that shape only (any shape, not only the list's)
+    if only and tuple(int(v) for v in only.split("x")) not in shapes:
+        shapes = [tuple(int(v) for v in only.split("x"))]
     for h, w in shapes:
         if only and only != f"{h}x{w}":
             continue
