@@ -6,7 +6,8 @@
 //   pass A  g_row_fwd  LP row pairs per workgroup: two-for-one real transform, split, pack
 //   pass B  g_col      TC adjacent packed columns per workgroup: column FFT, elementwise stage, inverse FFT
 //   pass C  g_row_inv  LP row pairs per workgroup: merge, inverse transform, store
-// Correctness-first: the tuned code is the power-of-two path.
+// Every kernel exists twice: LEAN (line plans of radices 2, 3, 4, 5, 8: half the registers, what a 5-smooth length gets)
+// and full (any factorisation). Numbers and what bounds them: DESIGN.md 5.3.
 #include <atomic>
 
 #include "gpt_common.h"

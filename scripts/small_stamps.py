@@ -26,7 +26,7 @@ def main():
     lib.gpt_debug_small_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.gpt_debug_small_stage_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     dev = torch.device("cuda:0")
-    for H, W, batch in [(1, 128, 1), (1, 100, 1), (35, 60, 1), (35, 60, 4096), (64, 64, 1)]:
+    for H, W, batch in [(1, 128, 1), (1, 100, 1), (35, 60, 1), (35, 60, 4096), (64, 64, 1), (100, 100, 1)]:
         g = torch.Generator(device="cpu").manual_seed(1)
         shape = (batch, H, W) if H > 1 else (batch, W)
         y = torch.randn(shape, dtype=torch.float64, generator=g).to(dev)
