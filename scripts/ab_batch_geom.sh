@@ -1,4 +1,5 @@
 #!/bin/bash
+# Column-kernel geometry (GPT_SUB_GEOM) against the number of lattices per launch at 4096^2: profiles/r03_j_batch_geom_ab.jsonl
 out=gpurun_out/r03j; mkdir -p $out; : > $out/batch_geom.jsonl
 for b in 1 4; do for g in 0 1 3 4; do
   GPT_SUB_GEOM=$g timeout -k 10 200 python bench.py --batch $b --steps 20 --warmup 3 --no-cpu-baseline --no-extra > $out/tmp.json 2> $out/tmp.err || { echo fail; tail -3 $out/tmp.err; exit 1; }
