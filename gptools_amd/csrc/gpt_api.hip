@@ -648,9 +648,11 @@ static double gamma_ratio(double nu, int dim1) {
 }
 
 // Kernel-fused log density: lpdf(y | loc, kernel(params) + nugget) with the reverse mode down
-// to the kernel parameters. Power-of-two lattices of 512..8192 rows evaluate the spectrum inside the column pass
-// (OP_LPDF_KVJP: no cov read, no d/dcov write); every other shape composes the existing kernels on library-owned
-// scratch (spectrum -> fused value + gradient -> kernel reverse mode), same results.
+// to the kernel parameters. One-workgroup lattices, power-of-two lattices of 512..8192 rows and the generic three-pass
+// path evaluate the spectrum inside their elementwise stage (OP_LPDF_KVJP: no cov read, no d/dcov write, the
+// parameter gradient finished by the last kernel); every other shape (and smoothness values other than 0.5 ... 5.5)
+// composes the existing kernels on library-owned scratch (spectrum -> fused value + gradient -> kernel reverse mode),
+// same results.
 int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx* c, int matern, double nu, const double* y, int64_t y_bs, const double* loc,
                                  int64_t loc_bs, const double* params, double nugget, int64_t H, int64_t W,
                                  int64_t batch, int dim1, double* lpdf, double* grad_y, double* params_bar,
@@ -669,7 +671,8 @@ int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx* c, int matern, double nu, const double
     const bool nu_ok = !matern || (nu <= 5.5 && nu - std::floor(nu) == 0.5 /* kern_eval */);
     const int path = path_for_shape(H, W);
     // (the 1-D functions: the one-workgroup kernel only -- its kern_prepare knows fft1.stan:154-176)
-    const bool fused = nu_ok && (path == 0 || (!dim1 && path == 1 && gpt_pow2_sub_radix(OP_LPDF_KVJP, (int)H, (int)W) != 0));
+    const bool fused = nu_ok && (path == 0 || (!dim1 && path == 1 && gpt_pow2_sub_radix(OP_LPDF_KVJP, (int)H, (int)W) != 0) ||
+                                 (!dim1 && path == 2));
     if (fused) {
         // both paths finish inside their last kernel (the one-workgroup kernel's last thread, finalize_block of pass C):
         // no combine launch, no scratch

@@ -186,7 +186,8 @@ __global__ void __launch_bounds__(G_COL_THREADS_MAX) g_col(LatArgs a, GenGeo g, 
     const int64_t b = blockIdx.y;
     const int H = a.H;
     const ZLayout L = make_layout(a);
-    const EwPtrs P = make_ptrs(a, b);
+    EwPtrs P = make_ptrs(a, b);
+    kern_prepare<OP>(a, P); // (the kernel-fused ops: this lattice's kernel parameters -> wave-uniform constants)
     // Workgroups go round the eight XCDs (each with an L2 of its own) in dispatch order: the tiles of one XCD are made
     // NEIGHBOURS in memory -- tile x of the grid is tile (x / 8) of the (x % 8)-th eighth of the columns -- so that the
     // workspace and `cov` lines that narrow tiles (tall lattices: 1 - 4 columns, 16 - 64 bytes of every 128-byte line)
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(G_COL_THREADS_MAX) g_col(LatArgs a, GenGeo g, 
     GMARK(0);
     // `cov` of the thread's entries (at most G_EPT: the tile has at most G_EPT * blockDim.x elements), asked for before the
     // workspace loads so that its latency passes behind theirs and the transform's, not in front of the elementwise stage
-    constexpr bool uses_cov = OP != OP_RFFT2 && OP != OP_INV_RFFT2;
+    constexpr bool uses_cov = OP != OP_RFFT2 && OP != OP_INV_RFFT2 && !op_is_kvjp(OP); // (those evaluate the kernel instead)
     double cpre[G_EPT];
     if (uses_cov) {
 #pragma unroll
@@ -266,11 +267,25 @@ __global__ void __launch_bounds__(G_COL_THREADS_MAX) g_col(LatArgs a, GenGeo g, 
     }
     if (OP != OP_RFFT2 && OP != OP_INV_RFFT2) {
         double s = acc.sum, mn = acc.mn;
+        double kk[3] = {acc.k0, acc.k1, acc.k2}; // (kernel-fused ops: the three sums of acc_kern, finalize_block turns them
+                                                 // into d / d(sigma, length_scale, period))
+        if (op_is_kvjp(OP)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { // (block_sum_min ends with a barrier-protected read by thread 0)
+                double t = kk[i], dummy = 0.0;
+                block_sum_min(t, dummy, red);
+                kk[i] = t;
+                __syncthreads();
+            }
+        }
         block_sum_min(s, mn, red);
         if (threadIdx.x == 0) {
             double* p = partials + ((int64_t)b * gridDim.x + blockIdx.x) * GPT_PART;
             p[0] = s;
-            p[1] = p[2] = p[3] = p[4] = 0.0;
+            p[1] = op_is_kvjp(OP) ? kk[0] : 0.0;
+            p[2] = op_is_kvjp(OP) ? kk[1] : 0.0;
+            p[3] = op_is_kvjp(OP) ? kk[2] : 0.0;
+            p[4] = 0.0;
             p[5] = mn;
         }
     }
@@ -421,6 +436,8 @@ hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partia
     case OP_INV_VJP: e = launch_col<OP_INV_VJP>(a, g, ws, partials, nblk, st); break;
     case OP_FWD_VJP: e = launch_col<OP_FWD_VJP>(a, g, ws, partials, nblk, st); break;
     case OP_LPDF_VJP_NOCOV: e = launch_col<OP_LPDF_VJP_NOCOV>(a, g, ws, partials, nblk, st); break;
+    case OP_LPDF_KVJP: e = launch_col<OP_LPDF_KVJP>(a, g, ws, partials, nblk, st); break;
+    case OP_LPDF_KVJP_EQ: e = launch_col<OP_LPDF_KVJP_EQ>(a, g, ws, partials, nblk, st); break;
     default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
@@ -428,8 +445,9 @@ hipError_t gpt_launch_generic(int op, const LatArgs& a, cplx* ws, double* partia
     if (op != OP_RFFT2 && op != OP_INV_RFFT2) {
         const bool lp = (op == OP_LPDF || op_is_lpdf_vjp(op) || op == OP_INV_VJP); // (OP_INV_VJP: the z prior)
         const double add = -0.5 * n * 1.8378770664093454836;
-        if (op_has_inv(op)) { // pass C adds the partials up
-            fin = FinArgs{partials, nblk, add, lp ? a.out_lpdf : nullptr, a.min_eig, nullptr, nullptr};
+        if (op_has_inv(op)) { // pass C adds the partials up (and finishes the kernel-parameter gradient)
+            fin = FinArgs{partials, nblk, add, lp ? a.out_lpdf : nullptr, a.min_eig, op_is_kvjp(op) ? a.kpar : nullptr,
+                          op_is_kvjp(op) ? a.kbar : nullptr};
         } else {
             e = gpt_launch_finalize(partials, nblk, a.batch, 1, add, lp ? a.out_lpdf : nullptr, a.min_eig, st);
             if (e != hipSuccess) return e;

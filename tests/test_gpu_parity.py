@@ -463,7 +463,8 @@ def test_subline_path_variants(fft):
         fft.gp_rfft2_lpdf_vjp(y, loc, bad)
 
 
-@pytest.mark.parametrize("shape", [(1024, 1024), (512, 2048), (35, 60), (100, 100), (128,)], ids=str)
+@pytest.mark.parametrize("shape", [(1024, 1024), (512, 2048), (35, 60), (100, 100), (128,),
+                                   (300, 210), (1000, 40), (121, 130), (2500, 6)], ids=str)  # (generic path: lean / full kernels)
 @pytest.mark.parametrize("kind,nu", [("matern", 1.5), ("matern", 2.5), ("matern", 0.9), ("expquad", 0.0)])
 def test_kernel_fused_lpdf(fft, shape, kind, nu):
     """gp_rfft2_lpdf over gp_periodic_*_cov_rfft2 + nugget without the spectrum in memory (power-of-two lattices of
