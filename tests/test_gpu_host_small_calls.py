@@ -82,7 +82,7 @@ def test_many_small_host_calls_in_a_row(fft, shape, layout_name):
             assert "not positive-definite" in ctx.error()
 
 
-@pytest.mark.parametrize("shape", [(1, 100), (35, 60), (64, 64), (256, 256)], ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("shape", [(1, 100), (35, 60), (64, 64), (256, 256), (120, 150)], ids=lambda s: f"{s[0]}x{s[1]}")
 @pytest.mark.parametrize("kind,nu", [("matern", 1.5), ("expquad", 0.0)])
 def test_kernel_parameter_host_forms(fft, shape, kind, nu):
     """gpt_gp_rfft2_lpdf_kernel_host and gpt_gp_inv_rfft2_obs_lpdf_kernel_host (column-major, as the Stan header calls
