@@ -170,6 +170,13 @@ static bool many_large_small_lattices(int op, const LatArgs& a) {
     return lds > 160 * 1024 / 3 && a.batch >= 2048;         // two
 }
 
+// The kernel-fused log density on power-of-two lattices WITHOUT a sub-line column kernel (256 rows): their whole-column
+// kernel has no OP_LPDF_KVJP, the generic path's has (256 x 256 x 64 lattices: 88 us there against 170 us for the
+// composition of spectrum, log density and spectrum reverse mode on the power-of-two path).
+static bool kvjp_on_generic(int op, int H, int W) {
+    return op_is_kvjp(op) && gpt_pow2_supported(H, W) && gpt_pow2_sub_radix(op, H, W) == 0 && gpt_generic_supported(H, W);
+}
+
 int run_lattice(gpt_ctx* c, int op, LatArgs a) {
     const bool armed = c->done_armed; // (one request, one launch: whatever happens below, it does not outlive this call)
     c->done_armed = false;
@@ -178,6 +185,7 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
     int rc;
     int path = path_for_shape(a.H, a.W);
     if (path == 0 && many_large_small_lattices(op, a)) path = 2;
+    if (path == 1 && kvjp_on_generic(op, a.H, a.W)) path = 2;
     if (path == 3) { // any-length path: its own plans (four-step / Bluestein), tables and scratch
         if (!c->anyn) c->anyn = gpt_anyn_create();
         return run_units(c, op, a, path, gpt_anyn_chunk(a.H, a.W), nullptr, nullptr, false);
@@ -672,7 +680,7 @@ int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx* c, int matern, double nu, const double
     const int path = path_for_shape(H, W);
     // (the 1-D functions: the one-workgroup kernel only -- its kern_prepare knows fft1.stan:154-176)
     const bool fused = nu_ok && (path == 0 || (!dim1 && path == 1 && gpt_pow2_sub_radix(OP_LPDF_KVJP, (int)H, (int)W) != 0) ||
-                                 (!dim1 && path == 2));
+                                 (!dim1 && path == 2) || (!dim1 && path == 1 && kvjp_on_generic(OP_LPDF_KVJP, (int)H, (int)W)));
     if (fused) {
         // both paths finish inside their last kernel (the one-workgroup kernel's last thread, finalize_block of pass C):
         // no combine launch, no scratch

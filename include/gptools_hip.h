@@ -232,8 +232,9 @@ int gpt_gp_periodic_matern_cov_rfft2_vjp(gpt_ctx*, double nu, int64_t height, in
  * H x (W/2+1) temporaries): lpdf[b] = gp_rfft2_lpdf(y[b] | loc, kernel(params[b]) + nugget) with the reverse mode
  * grad_y[batch][H][W] and params_bar[batch][5] (or [3] for dim1; may be NULL) = d lpdf / d (sigma, length_scale,
  * period); nu and the nugget are data. `matern` 0: periodic squared exponential, else Matern with smoothness nu.
- * Lattices that fit a workgroup, power-of-two lattices of 512..8192 rows and the generic three-pass path (gpt_path_for_shape
- * 0, 1, 2) evaluate the spectrum inside their elementwise stage and never store it (exp-quad, Matern with nu = 0.5 ... 5.5);
+ * Lattices that fit a workgroup, power-of-two lattices (those of 256 rows on the generic path's kernels) and the generic
+ * three-pass path (gpt_path_for_shape 0, 1, 2) evaluate the spectrum inside their elementwise stage and never store it
+ * (exp-quad, Matern with nu = 0.5 ... 5.5);
  * the any-length path and other smoothness values compose the existing kernels on library-owned scratch with identical
  * results. */
 int gpt_gp_rfft2_lpdf_kernel_vjp(gpt_ctx*, int matern, double nu, const double* y, int64_t y_bs, const double* loc,

@@ -15,7 +15,10 @@ from bench_small import time_gpu  # noqa: E402
 from gptools_amd import fft  # noqa: E402
 
 dev = torch.device("cuda", 0)
-for h, w, b in [(128, 128, 1), (128, 128, 64), (192, 192, 64), (300, 210, 64), (1000, 1000, 8), (3000, 3000, 2)]:
+cases = [(128, 128, 1), (128, 128, 64), (192, 192, 64), (300, 210, 64), (1000, 1000, 8), (3000, 3000, 2)]
+if len(sys.argv) > 1:  # "HxWxB,HxWxB,..."
+    cases = [tuple(int(v) for v in c.split("x")) for c in sys.argv[1].split(",")]
+for h, w, b in cases:
     y = torch.randn(b, h, w, dtype=torch.float64, device=dev)
     loc = torch.zeros(h, w, dtype=torch.float64, device=dev)
     sigma = torch.linspace(1.2, 1.4, b, dtype=torch.float64, device=dev)

@@ -464,7 +464,8 @@ def test_subline_path_variants(fft):
 
 
 @pytest.mark.parametrize("shape", [(1024, 1024), (512, 2048), (35, 60), (100, 100), (128,),
-                                   (300, 210), (1000, 40), (121, 130), (2500, 6)], ids=str)  # (generic path: lean / full kernels)
+                                   (300, 210), (1000, 40), (121, 130), (2500, 6),  # (generic path: lean / full kernels)
+                                   (256, 256), (256, 1024)], ids=str)  # (no sub-line column kernel: generic path's kernels)
 @pytest.mark.parametrize("kind,nu", [("matern", 1.5), ("matern", 2.5), ("matern", 0.9), ("expquad", 0.0)])
 def test_kernel_fused_lpdf(fft, shape, kind, nu):
     """gp_rfft2_lpdf over gp_periodic_*_cov_rfft2 + nugget without the spectrum in memory (power-of-two lattices of
