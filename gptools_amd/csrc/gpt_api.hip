@@ -177,6 +177,22 @@ static bool kvjp_on_generic(int op, int H, int W) {
     return op_is_kvjp(op) && gpt_pow2_supported(H, W) && gpt_pow2_sub_radix(op, H, W) == 0 && gpt_generic_supported(H, W);
 }
 
+// The power-of-two kernels are built for throughput: few, fat workgroups (a 256 x 256 lattice is 8 row and a handful of
+// column workgroups), so a launch of one or a few SMALL power-of-two lattices -- what a single Stan chain sends -- is a
+// long chain of phases on a handful of CUs. The generic path's kernels (many small workgroups, lean instantiations: every
+// power of two is 5-smooth) have the lower latency there. Measured (profiles/r03_x_pow2_vs_generic_few.jsonl, value +
+// gradients, us per launch, power-of-two / generic kernels): 256^2: 1 lattice 60.7 / 31.8, 16: 74.9 / 40.8, 64: 98.1 /
+// 74.3, 1024: 1039 / 1073; 512^2: 1: 40.0 / 35.0, 4: 48.8 / 43.5, 16: 64.4 / 75.4; 1024^2: 1: 66.0 / 47.8, 4: 83.1 / 84.0,
+// 16: 297 / 322; 1024 x 256: 1: 52.1 / 37.9, 4: 62.3 / 47.0; 2048^2 and larger: the power-of-two kernels at every count.
+// Rule: launches of up to 2^20 lattice points in all (2^23 at 256 rows, whose power-of-two column kernel is the
+// whole-column one) take the generic kernels. GPT_POW2_SMALL_TO_GENERIC=0 (read per call) keeps them on the tuned path.
+static bool few_pow2_lattices(const LatArgs& a) {
+    const char* e = getenv("GPT_POW2_SMALL_TO_GENERIC");
+    if ((e && e[0] == '0') || a.H > 1024 || !gpt_generic_supported(a.H, a.W)) return false;
+    const int64_t points = a.batch * (int64_t)a.H * (int64_t)a.W;
+    return points <= (a.H <= 256 ? (int64_t)1 << 23 : (int64_t)1 << 20);
+}
+
 int run_lattice(gpt_ctx* c, int op, LatArgs a) {
     const bool armed = c->done_armed; // (one request, one launch: whatever happens below, it does not outlive this call)
     c->done_armed = false;
@@ -186,6 +202,7 @@ int run_lattice(gpt_ctx* c, int op, LatArgs a) {
     int path = path_for_shape(a.H, a.W);
     if (path == 0 && many_large_small_lattices(op, a)) path = 2;
     if (path == 1 && kvjp_on_generic(op, a.H, a.W)) path = 2;
+    if (path == 1 && few_pow2_lattices(a)) path = 2;
     if (path == 3) { // any-length path: its own plans (four-step / Bluestein), tables and scratch
         if (!c->anyn) c->anyn = gpt_anyn_create();
         return run_units(c, op, a, path, gpt_anyn_chunk(a.H, a.W), nullptr, nullptr, false);

@@ -328,8 +328,11 @@ BIG_SHAPES = [(256, 256), (256, 512), (512, 256), (1024, 256), (2048, 512), (512
 
 
 @pytest.mark.parametrize("shape", BIG_SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
-def test_three_pass_path_vs_oracle(fft, shape):
+def test_three_pass_path_vs_oracle(fft, shape, monkeypatch):
     """Every lattice function on the three-pass kernels, batch of 2, against the oracle."""
+    # (launches of a few small power-of-two lattices would take the generic kernels, gpt_api.hip few_pow2_lattices: this test
+    # is about each path's own kernels; the re-routed launches are test_few_small_power_of_two_lattices below)
+    monkeypatch.setenv("GPT_POW2_SMALL_TO_GENERIC", "0")
     h, w = shape
     assert fft.path_for_shape(h, w) in (1, 2)
     rng = np.random.default_rng(100 * h + w)
@@ -361,6 +364,32 @@ def test_three_pass_path_vs_oracle(fft, shape):
     bad[h - 1, 0] = -1.0
     with pytest.raises(ValueError, match="not positive-definite"):
         fft.gp_rfft2_lpdf(y, loc, bad)
+
+
+@pytest.mark.parametrize("shape", [(256, 256), (256, 512), (512, 256), (1024, 256), (1024, 1024), (256, 4096)],
+                         ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("batch", [1, 3])
+def test_few_small_power_of_two_lattices(fft, shape, batch, monkeypatch):
+    """A launch of one or a few small power-of-two lattices runs on the generic path's kernels (lower latency; gpt_api.hip
+    few_pow2_lattices), GPT_POW2_SMALL_TO_GENERIC=0 keeps it on the power-of-two kernels: both against the oracle."""
+    h, w = shape
+    rng = np.random.default_rng(5 * h + w + batch)
+    y = rng.normal(size=(batch, h, w))
+    loc = rng.normal(size=(h, w))
+    cov = np.exp(0.3 * rng.normal(size=(batch, h, w // 2 + 1)))
+    z = rng.normal(size=(batch, h, w))
+    want = [o.gp_rfft2_lpdf_vjp(y[i], loc, cov[i]) for i in range(batch)]
+    f_o = o.gp_inv_rfft2(z[batch - 1], loc, cov[batch - 1])
+    z_o = o.gp_rfft2(y[0], loc, cov[0])
+    for knob in ("1", "0"):
+        monkeypatch.setenv("GPT_POW2_SMALL_TO_GENERIC", knob)
+        lp, gy, gc = fft.gp_rfft2_lpdf_vjp(y, loc, cov)
+        for i in range(batch):
+            close(lp[i], want[i][0])
+            close(gy[i], want[i][1])
+            close(gc[i], want[i][2])
+        close(fft.gp_inv_rfft2(z, loc, cov)[batch - 1], f_o)
+        close(fft.gp_rfft2(y, loc, cov)[0], z_o)
 
 
 def test_many_large_one_workgroup_lattices_take_the_generic_path(fft):
