@@ -292,7 +292,7 @@ def generic_path_extra(fft, device):
     rec = {}
     g = torch.Generator(device=device)
     g.manual_seed(11)
-    for h, w, B in ((1000, 1000, 8), (3000, 3000, 2), (192, 192, 64), (72, 72, 4096)):
+    for h, w, B in ((1000, 1000, 8), (3000, 3000, 2), (192, 192, 64), (72, 72, 4096), (256, 256, 1)):
         y = torch.randn(B, h, w, dtype=torch.float64, device=device, generator=g)
         loc = torch.zeros(h, w, dtype=torch.float64, device=device)
         cov = torch.exp(0.3 * torch.randn(B, h, w // 2 + 1, dtype=torch.float64, device=device, generator=g))
@@ -311,6 +311,7 @@ def generic_path_extra(fft, device):
                            "frac": B * b_alg / sec / HBM_PEAK, "finite": bool(torch.isfinite(out[0]).all())}
         del y, cov, out
     rec["72x72"]["note"] = "path 0 by shape; launches of >= 384 such lattices run on the generic path (gpt_api.hip)"
+    rec["256x256"]["note"] = "path 1 by shape; launches of <= 2^23 points at 256 rows run on the generic path's kernels (latency)"
     torch.cuda.empty_cache()
     return rec
 
